@@ -1,0 +1,171 @@
+/*
+ * pointops2_hip.h — C ABI of libpointops2_hip.so, the MI355X (gfx950) implementation of the
+ * Stratified Transformer's pointops2 hot path.
+ *
+ * PART 1 are the reference's own raw-pointer launchers (the "true C ABI" of lib/pointops2,
+ * SURVEY.md §8b seam B2): same names, same argument order and meaning.  Every pointer is a
+ * DEVICE pointer to a contiguous fp32 / int32 array.  Ownership follows the reference: the caller
+ * allocates every output (and zero-fills it where the reference does, see each entry); the library
+ * borrows the pointers for the duration of the launch, allocates nothing and returns void.
+ *
+ * Differences from the reference, all "stricter is compatible":
+ *   - launches go to the stream set with pointops2_set_stream() (thread-local; default: the NULL
+ *     stream, which is what the reference's <<<grid, block, 0>>> launches use);
+ *   - instead of `throw "d != 16 and d != 32"` (attention_cuda_kernel_v2.cu:116) an unsupported
+ *     argument records an error readable with pointops2_last_error(); the call is then a no-op;
+ *   - outputs are fully written by the kernels (the caller's zero-fill is harmless, not required),
+ *     except where noted "accumulates".
+ *
+ * PART 2 are the additional native entry points this build adds on the same path (segment softmax
+ * = the torch_scatter.scatter_softmax call of the model, CSC transposition used by the backward
+ * kernels, the on-device index build, cooperative FPS).
+ */
+#ifndef POINTOPS2_HIP_H
+#define POINTOPS2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* runtime plumbing                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+/* hipStream_t as void*.  Thread-local.  NULL = legacy default stream. */
+void pointops2_set_stream(void *hip_stream);
+void *pointops2_get_stream(void);
+/* NULL when the last call on this thread succeeded; otherwise a static message.  Reading clears. */
+const char *pointops2_last_error(void);
+/* library/ABI version, bumped when a signature changes */
+int pointops2_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* PART 1 — the reference's launcher set                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* sampling/sampling_cuda_kernel.h:14  — furthest point sampling per batch element.
+ * n = largest batch element (selects the reference's block size, which fixes its tie rule);
+ * xyz [N,3]; offset/new_offset [b] cumulative ends; tmp [N] scratch PRE-FILLED with 1e10;
+ * idx [new_offset[b-1]] out. */
+void furthestsampling_cuda_launcher(int b, int n, const float *xyz, const int *offset,
+                                    const int *new_offset, float *tmp, int *idx);
+
+/* knnquery/knnquery_cuda_kernel.h:14 — exact kNN, ascending; dist2 = SQUARED distances. nsample <= 100. */
+void knnquery_cuda_launcher(int m, int nsample, const float *xyz, const float *new_xyz,
+                            const int *offset, const int *new_offset, int *idx, float *dist2);
+
+/* grouping/grouping_cuda_kernel.h:14-15 — gather rows / scatter-add (grad_input accumulates). */
+void grouping_forward_cuda_launcher(int m, int nsample, int c, const float *input, const int *idx, float *output);
+void grouping_backward_cuda_launcher(int m, int nsample, int c, const float *grad_output, const int *idx, float *grad_input);
+
+/* interpolation/interpolation_cuda_kernel.h:34-35 — k-NN weighted sum (output / grad_input accumulate). */
+void interpolation_forward_cuda_launcher(int n, int c, int k, const float *input, const int *idx, const float *weight, float *output);
+void interpolation_backward_cuda_launcher(int n, int c, int k, const float *grad_output, const int *idx, const float *weight, float *grad_input);
+
+/* attention/attention_cuda_kernel.h:17-21 — pair-indexed (v1) forms; outputs ACCUMULATE (atomics in
+ * the reference), so the caller's zero-fill is required. */
+void attention_step1_forward_cuda_launcher(int N, int M, int h, int C, const float *q, const float *k,
+                                           const int *index0, const int *index1, float *attn);
+void attention_step1_backward_cuda_launcher(int N, int M, int h, int C, const float *grad_out,
+                                            const int *index0, const int *index1, const float *q,
+                                            const float *k, float *grad_q, float *grad_k);
+void attention_step2_forward_cuda_launcher(int N, int M, int h, int C, const float *attn, const float *v,
+                                           const int *index0, const int *index1, float *output);
+void attention_step2_backward_cuda_launcher(int N, int M, int h, int C, const float *grad_out,
+                                            const int *index0, const int *index1, const float *attn,
+                                            const float *v, float *grad_attn, float *grad_v);
+
+/* attention_v2/attention_cuda_kernel_v2.h:19-23 — CSR forms.  index0_offsets [N+1]; index1 [M];
+ * n_max = longest segment (<= 1024, pointops.py:150).  C/h must be 16 or 32.
+ * backward: grad_q fully written; grad_k ACCUMULATES (pre-zeroed by the caller). */
+void attention_step1_forward_cuda_launcher_v2(int N, int M, int h, int C, const unsigned int n_max,
+                                              const float *q, const float *k, const int *index0_offsets,
+                                              const int *index1, float *attn);
+void attention_step1_backward_cuda_launcher_v2(int N, int M, int h, int C, const unsigned int n_max,
+                                               const float *grad_out, const int *index0_offsets,
+                                               const int *index1, const float *q, const float *k,
+                                               float *grad_q, float *grad_k);
+void attention_step2_forward_cuda_launcher_v2(int N, int M, int h, int C, const float *attn, const float *v,
+                                              const int *index0, const int *index1, float *output);
+void attention_step2_backward_cuda_launcher_v2(int N, int M, int h, int C, const float *grad_out,
+                                               const int *index0, const int *index1, const float *attn,
+                                               const float *v, float *grad_attn, float *grad_v);
+
+/* rpe/relative_pos_encoding_cuda_kernel.h:17-21 — v1 single-table forms (outputs accumulate). */
+void dot_prod_with_idx_forward_cuda_launcher(int N, int M, int h, int hdim, const float *q, const int *index,
+                                             const float *table, const int *rel_idx, float *output);
+void dot_prod_with_idx_backward_cuda_launcher(int N, int M, int h, int hdim, const float *grad_out,
+                                              const float *q, const int *index, const float *table,
+                                              const int *rel_idx, float *grad_q, float *grad_table);
+void attention_step2_with_rel_pos_value_forward_cuda_launcher(int N, int M, int h, int hdim, const float *attn,
+                                                              const float *v, const int *index0, const int *index1,
+                                                              const float *table, const int *rel_idx, float *output);
+void attention_step2_with_rel_pos_value_backward_cuda_launcher(int N, int M, int h, int hdim, const float *grad_out,
+                                                               const int *index0, const int *index1, const float *attn,
+                                                               const float *v, const float *table, const int *rel_idx,
+                                                               float *grad_attn, float *grad_v, float *grad_table);
+
+/* rpe_v2/relative_pos_encoding_cuda_kernel_v2.h:22-29 — CSR forms.  table [L,h,hdim,3]; rel_idx [M,3].
+ * hdim must be 16 or 32.  backward: grad_q / grad_attn fully written; grad_k / grad_v / table grads
+ * ACCUMULATE (pre-zeroed by the caller).  The table length L is not part of the reference signature:
+ * set it with pointops2_set_table_rows() before a *_backward_* call (default 2*1024 rows is never
+ * exceeded by the reference's models; the Python layer always sets it). */
+void dot_prod_with_idx_forward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max, int T, const float *q,
+                                                const int *index_q, const float *k, const int *index_k,
+                                                const float *table_q, const float *table_k, const int *rel_idx,
+                                                const int *rel_idx_offsets, const int *sort_indices, float *output);
+void dot_prod_with_idx_backward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max, int T, const float *grad_out,
+                                                 const float *q, const int *index_q, const float *k, const int *index_k,
+                                                 const float *table_q, const float *table_k, const int *rel_idx,
+                                                 const int *rel_idx_offsets, const int *sort_indices, float *grad_q,
+                                                 float *grad_k, float *grad_table_q, float *grad_table_k);
+void dot_prod_with_idx_forward_cuda_launcher_v3(int N, int M, int h, int hdim, int n_max, const float *q,
+                                                const int *index_q_offsets, const float *k, const int *index_k,
+                                                const float *table_q, const float *table_k, const int *rel_idx,
+                                                float *output);
+void dot_prod_with_idx_backward_cuda_launcher_v3(int N, int M, int h, int hdim, int n_max, const float *grad_out,
+                                                 const float *q, const int *index_q_offsets, const float *k,
+                                                 const int *index_k, const float *table_q, const float *table_k,
+                                                 const int *rel_idx, float *grad_q, float *grad_k,
+                                                 float *grad_table_q, float *grad_table_k);
+void attention_step2_with_rel_pos_value_forward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max,
+                                                                 const float *attn, const float *v,
+                                                                 const int *index0_offsets, const int *index1,
+                                                                 const float *table, const int *rel_idx, float *output);
+void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max,
+                                                                  const float *grad_out, const int *index0_offsets,
+                                                                  const int *index1, const float *attn, const float *v,
+                                                                  const float *table, const int *rel_idx,
+                                                                  float *grad_attn, float *grad_v, float *grad_table);
+
+/* ------------------------------------------------------------------------------------------ */
+/* PART 2 — additional entry points of this build                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Rows L of the [L,h,hdim,3] tables for the next *_v2/_v3 rel-pos call on this thread. */
+void pointops2_set_table_rows(int L);
+
+/* Key-major ("CSC") transposition of a CSR pair list, used by the backward kernels instead of
+ * global float atomics.  When set (thread-local, cleared with NULLs), the *_backward_* launchers
+ * above gather by key; otherwise they build a temporary one themselves in `workspace`.
+ *   csc_offsets [N+1], csc_pair [M] (pair id m, ascending per key), csc_query [M] (query of m). */
+size_t pointops2_csc_workspace_bytes(int N, int M);
+void pointops2_csc_build(int N, int M, const int *index0_offsets, const int *index1,
+                         int *csc_offsets, int *csc_pair, int *csc_query,
+                         void *workspace, size_t workspace_bytes);
+void pointops2_set_csc(const int *csc_offsets, const int *csc_pair, const int *csc_query);
+
+/* torch_scatter.scatter_softmax(src [M,h], index_0, dim=0) over CSR segments
+ * (model/stratified_transformer.py:205) and its backward. */
+void segment_softmax_forward_launcher(int N, int M, int h, const float *src, const int *offsets, float *out);
+void segment_softmax_backward_launcher(int N, int M, int h, const float *out, const float *grad_out,
+                                       const int *offsets, float *grad_src);
+/* expands CSR offsets to the per-pair query id (index_0) */
+void csr_expand_launcher(int N, int M, const int *offsets, int *index0);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTOPS2_HIP_H */

@@ -1,0 +1,87 @@
+// Shared plumbing of libpointops2_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "../../include/pointops2_hip.h"
+
+namespace p2 {
+
+// ---- per-thread launch state (pointops2_set_stream / _set_table_rows / _set_csc) ----
+struct LaunchState {
+    hipStream_t stream = nullptr;
+    const char *error = nullptr;
+    int table_rows = 0;
+    const int *csc_offsets = nullptr;
+    const int *csc_pair = nullptr;
+    const int *csc_query = nullptr;
+};
+LaunchState &state();
+
+inline void set_error(const char *msg) { state().error = msg; }
+
+inline bool check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        return false;
+    }
+    return true;
+}
+
+constexpr int WAVE = 64;
+constexpr int kNumCU = 256;  // MI355X
+
+// Dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (gfx950: 160 KiB per CU).
+template <typename K>
+inline void allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+inline int64_t div_up64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers ----
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void stg4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
+    return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
+}
+__device__ __forceinline__ float4 scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// butterfly sum over the lanes whose ids differ only in bits [LO, HI) of the lane id
+template <int LO_STRIDE, int HI_STRIDE>
+__device__ __forceinline__ float xor_sum(float v) {
+#pragma unroll
+    for (int s = LO_STRIDE; s < HI_STRIDE; s <<= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+template <int LO_STRIDE, int HI_STRIDE>
+__device__ __forceinline__ float4 xor_sum4(float4 v) {
+#pragma unroll
+    for (int s = LO_STRIDE; s < HI_STRIDE; s <<= 1) {
+        v.x += __shfl_xor(v.x, s, 64);
+        v.y += __shfl_xor(v.y, s, 64);
+        v.z += __shfl_xor(v.z, s, 64);
+        v.w += __shfl_xor(v.w, s, 64);
+    }
+    return v;
+}
+
+// Geometry of the per-query segment walkers: a head vector of D floats is spread over LPG lanes
+// (one float4 each); a wave therefore holds PPW pairs of one query side by side.
+template <int D>
+struct Geo {
+    static constexpr int LPG = D / 4;     // lanes per (pair, head)
+    static constexpr int PPW = 64 / LPG;  // pairs per wave pass
+};
+
+}  // namespace p2

@@ -1,0 +1,158 @@
+// Launch state, row gathers (grouping / interpolation) and the CSR <-> key-major (CSC) transposition.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace p2 {
+
+LaunchState &state() {
+    static thread_local LaunchState s;
+    return s;
+}
+
+// ---- grouping (grouping_cuda_kernel.cu:5-25) / interpolation (interpolation_cuda_kernel.cu:5-33) ----
+__global__ void grouping_fwd_kernel(int64_t total, int c, const float *__restrict__ input, const int *__restrict__ idx,
+                                    float *__restrict__ output) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    output[t] = input[(size_t)idx[t / c] * c + t % c];
+}
+__global__ void grouping_bwd_kernel(int64_t total, int c, const float *__restrict__ go, const int *__restrict__ idx,
+                                    float *__restrict__ gi) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    atomicAdd(gi + (size_t)idx[t / c] * c + t % c, go[t]);
+}
+__global__ void interp_fwd_kernel(int n, int c, int k, const float *__restrict__ input, const int *__restrict__ idx,
+                                  const float *__restrict__ weight, float *__restrict__ output) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * c) return;
+    const int ci = t % c, ni = t / c;
+    float o = output[t];
+    for (int i = 0; i < k; i++) o += input[(size_t)idx[ni * k + i] * c + ci] * weight[ni * k + i];
+    output[t] = o;
+}
+__global__ void interp_bwd_kernel(int n, int c, int k, const float *__restrict__ go, const int *__restrict__ idx,
+                                  const float *__restrict__ weight, float *__restrict__ gi) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * c) return;
+    const int ci = t % c, ni = t / c;
+    for (int i = 0; i < k; i++) atomicAdd(gi + (size_t)idx[ni * k + i] * c + ci, go[t] * weight[ni * k + i]);
+}
+
+// ---- CSR helpers ----
+__global__ __launch_bounds__(256) void csr_expand_kernel(int N, const int *__restrict__ offs, int *__restrict__ index0) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= N) return;
+    const int s = offs[qi], e = offs[qi + 1];
+    for (int m = s + lane; m < e; m += 64) index0[m] = qi;
+}
+__global__ void iota_kernel(int M, int *v) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) v[t] = t;
+}
+// after the stable sort by key: segment starts per key (empty keys included) and the query of each pair
+__global__ void csc_finish_kernel(int N, int M, const int *__restrict__ sorted_keys, const int *__restrict__ csc_pair,
+                                  const int *__restrict__ index0, int *__restrict__ csc_offsets, int *__restrict__ csc_query) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    const int kcur = sorted_keys[t];
+    const int kprev = t == 0 ? -1 : sorted_keys[t - 1];
+    for (int kk = kprev + 1; kk <= kcur; kk++) csc_offsets[kk] = t;
+    if (t == M - 1)
+        for (int kk = kcur + 1; kk <= N; kk++) csc_offsets[kk] = M;
+    csc_query[t] = index0[csc_pair[t]];
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static int key_bits(int N) {
+    int b = 1;
+    while ((1ll << b) < (long long)N) b++;
+    return b;
+}
+static size_t cub_sort_bytes(int N, int M) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int *)nullptr, (int *)nullptr, (const int *)nullptr,
+                                       (int *)nullptr, M, 0, key_bits(N), (hipStream_t) nullptr);
+    return bytes;
+}
+
+}  // namespace p2
+
+using namespace p2;
+
+extern "C" {
+
+void pointops2_set_stream(void *hip_stream) { state().stream = reinterpret_cast<hipStream_t>(hip_stream); }
+void *pointops2_get_stream(void) { return reinterpret_cast<void *>(state().stream); }
+const char *pointops2_last_error(void) {
+    const char *e = state().error;
+    state().error = nullptr;
+    return e;
+}
+int pointops2_abi_version(void) { return 1; }
+void pointops2_set_table_rows(int L) { state().table_rows = L; }
+void pointops2_set_csc(const int *csc_offsets, const int *csc_pair, const int *csc_query) {
+    LaunchState &s = state();
+    s.csc_offsets = csc_offsets;
+    s.csc_pair = csc_pair;
+    s.csc_query = csc_query;
+}
+
+void grouping_forward_cuda_launcher(int m, int nsample, int c, const float *input, const int *idx, float *output) {
+    const int64_t total = (int64_t)m * nsample * c;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(grouping_fwd_kernel, dim3(div_up64(total, 256)), dim3(256), 0, state().stream, total, c, input, idx, output);
+    check_launch();
+}
+void grouping_backward_cuda_launcher(int m, int nsample, int c, const float *grad_output, const int *idx, float *grad_input) {
+    const int64_t total = (int64_t)m * nsample * c;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(grouping_bwd_kernel, dim3(div_up64(total, 256)), dim3(256), 0, state().stream, total, c, grad_output, idx, grad_input);
+    check_launch();
+}
+void interpolation_forward_cuda_launcher(int n, int c, int k, const float *input, const int *idx, const float *weight, float *output) {
+    if ((int64_t)n * c <= 0) return;
+    hipLaunchKernelGGL(interp_fwd_kernel, dim3(div_up64((int64_t)n * c, 256)), dim3(256), 0, state().stream, n, c, k, input, idx, weight, output);
+    check_launch();
+}
+void interpolation_backward_cuda_launcher(int n, int c, int k, const float *grad_output, const int *idx, const float *weight, float *grad_input) {
+    if ((int64_t)n * c <= 0) return;
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(div_up64((int64_t)n * c, 256)), dim3(256), 0, state().stream, n, c, k, grad_output, idx, weight, grad_input);
+    check_launch();
+}
+
+void csr_expand_launcher(int N, int M, const int *offsets, int *index0) {
+    if (N <= 0 || M <= 0) return;
+    hipLaunchKernelGGL(csr_expand_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, offsets, index0);
+    check_launch();
+}
+
+// workspace layout: [index0 M][iota M][sorted keys M][hipcub temp]
+size_t pointops2_csc_workspace_bytes(int N, int M) {
+    if (N <= 0 || M <= 0) return 0;
+    return 3 * align256((size_t)M * sizeof(int)) + align256(cub_sort_bytes(N, M));
+}
+
+void pointops2_csc_build(int N, int M, const int *index0_offsets, const int *index1,
+                         int *csc_offsets, int *csc_pair, int *csc_query, void *workspace, size_t workspace_bytes) {
+    if (N <= 0 || M <= 0) return;
+    if (workspace_bytes < pointops2_csc_workspace_bytes(N, M)) { set_error("pointops2_csc_build: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    char *ws = reinterpret_cast<char *>(workspace);
+    const size_t seg = align256((size_t)M * sizeof(int));
+    int *index0 = reinterpret_cast<int *>(ws);
+    int *iota = reinterpret_cast<int *>(ws + seg);
+    int *keys = reinterpret_cast<int *>(ws + 2 * seg);
+    void *cub_tmp = ws + 3 * seg;
+    size_t cub_bytes = workspace_bytes - 3 * seg;
+    hipLaunchKernelGGL(csr_expand_kernel, dim3(div_up(N, 4)), dim3(256), 0, st, N, index0_offsets, index0);
+    hipLaunchKernelGGL(iota_kernel, dim3(div_up(M, 256)), dim3(256), 0, st, M, iota);
+    // stable LSD radix sort: per key the pair ids stay ascending => deterministic summation order
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, index1, keys, (const int *)iota, csc_pair, M, 0, key_bits(N), st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(csc_finish_kernel, dim3(div_up(M, 256)), dim3(256), 0, st, N, M, keys, csc_pair, index0, csc_offsets, csc_query);
+    check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,674 @@
+// A2 (contextual relative-position bias) and A4 (AV with relative-position value), gfx950.
+//
+// Replaces lib/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.cu:247-540 (v3 bias, v2
+// AV) and lib/pointops2/src/rpe/relative_pos_encoding_cuda_kernel.cu (v1 forms) behind the same
+// launchers.
+//
+// Design
+//  * The [L,h,D,3] tables are tiny (12 KB per head at L=64, D=16) and hit by every pair, so each
+//    workgroup stages the heads it works on in LDS, TRANSPOSED to [head][axis][row][D]: the D
+//    floats of one (axis,row,head) become one contiguous 64/128-byte run and a lane fetches its
+//    quarter with a single ds_read_b128 (the reference does 3*D scattered 4-byte global loads per
+//    pair and table).  Workgroups are persistent (grid-stride over queries) so the staging cost is
+//    paid once per CU, and the grid's second dimension walks head groups that fit the LDS budget.
+//  * Same wave-per-query walker as attention.hip (LPG lanes per head vector, PPW pairs per pass).
+//  * Backward: table gradients are accumulated in LDS (ds_add_f32) and flushed once per workgroup
+//    with global atomics — the reference issues 6-8 global atomics per (pair, channel) into a
+//    9216-float table.  Key-side gradients are produced by key through the CSC view
+//    (pointops2_set_csc); without it the by-query kernel falls back to global atomics.
+#include "common.h"
+
+namespace p2 {
+
+constexpr size_t kLdsBudget = 72 * 1024;  // two workgroups per CU
+
+// LDS image of one table slice: [hg][3][L][D]
+template <int D>
+__device__ __forceinline__ void stage_table(float *lds, const float *__restrict__ tab, int L, int h, int h0, int hgn) {
+    const int total = hgn * 3 * L * D;
+    for (int x = threadIdx.x; x < total; x += blockDim.x) {
+        const int i = x % D;
+        const int r = (x / D) % L;
+        const int ax = (x / (D * L)) % 3;
+        const int t = x / (D * L * 3);
+        lds[x] = tab[(((size_t)r * h + (h0 + t)) * D + i) * 3 + ax];
+    }
+}
+template <int D>
+__device__ __forceinline__ void zero_lds(float *lds, int n) {
+    for (int x = threadIdx.x; x < n; x += blockDim.x) lds[x] = 0.f;
+}
+// adds the LDS gradient image back into the global [L,h,D,3] table
+template <int D>
+__device__ __forceinline__ void flush_table(const float *lds, float *__restrict__ gtab, int L, int h, int h0, int hgn) {
+    const int total = hgn * 3 * L * D;
+    for (int x = threadIdx.x; x < total; x += blockDim.x) {
+        const float v = lds[x];
+        if (v != 0.f) {
+            const int i = x % D;
+            const int r = (x / D) % L;
+            const int ax = (x / (D * L)) % 3;
+            const int t = x / (D * L * 3);
+            atomicAdd(gtab + (((size_t)r * h + (h0 + t)) * D + i) * 3 + ax, v);
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ const float4 *trow(const float *lds, int L, int t, int ax, int r, int c) {
+    return reinterpret_cast<const float4 *>(lds + (((size_t)t * 3 + ax) * L + r) * D + 4 * c);
+}
+// T(m, head t)[4c..4c+3] = tab[r0,.,.,0] + tab[r1,.,.,1] + tab[r2,.,.,2]   (left to right, as the reference)
+template <int D>
+__device__ __forceinline__ float4 tsum(const float *lds, int L, int t, int r0, int r1, int r2, int c) {
+    return add4(add4(*trow<D>(lds, L, t, 0, r0, c), *trow<D>(lds, L, t, 1, r1, c)), *trow<D>(lds, L, t, 2, r2, c));
+}
+template <int D>
+__device__ __forceinline__ void tadd(float *lds, int L, int t, int r0, int r1, int r2, int c, float4 v) {
+    float *a0 = lds + (((size_t)t * 3 + 0) * L + r0) * D + 4 * c;
+    float *a1 = lds + (((size_t)t * 3 + 1) * L + r1) * D + 4 * c;
+    float *a2 = lds + (((size_t)t * 3 + 2) * L + r2) * D + 4 * c;
+    atomicAdd(a0 + 0, v.x); atomicAdd(a0 + 1, v.y); atomicAdd(a0 + 2, v.z); atomicAdd(a0 + 3, v.w);
+    atomicAdd(a1 + 0, v.x); atomicAdd(a1 + 1, v.y); atomicAdd(a1 + 2, v.z); atomicAdd(a1 + 3, v.w);
+    atomicAdd(a2 + 0, v.x); atomicAdd(a2 + 1, v.y); atomicAdd(a2 + 2, v.z); atomicAdd(a2 + 3, v.w);
+}
+__device__ __forceinline__ int clampr(int r, int L) { return min(max(r, 0), L - 1); }
+
+#define P2_WALK_PROLOGUE                                                            \
+    constexpr int LPG = Geo<D>::LPG, PPW = Geo<D>::PPW;                             \
+    extern __shared__ float lds[];                                                  \
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                     \
+    const int C = h * D;                                                            \
+    const int p = lane / LPG, c = lane % LPG;                                       \
+    const int h0 = blockIdx.y * HG;                                                 \
+    const int hgn = min(HG, h - h0);                                                \
+    const int tsz = hgn * 3 * L * D;                                                \
+    (void)PPW; (void)p; (void)tsz; (void)C; (void)c; (void)wave;
+
+// ------------------------------------------------------------------------------------------------
+// A2 forward: out[m,hh] = sum_i q[query,hh,i]*Tq(m,hh,i) + k[idx_k[m],hh,i]*Tk(m,hh,i)
+// ------------------------------------------------------------------------------------------------
+template <int D, int HG>
+__global__ __launch_bounds__(256) void a2_fwd_kernel(int N, int h, int L, const float *__restrict__ q,
+                                                     const int *__restrict__ offs, const float *__restrict__ k,
+                                                     const int *__restrict__ idx_k, const float *__restrict__ table_q,
+                                                     const float *__restrict__ table_k, const int *__restrict__ rel,
+                                                     float *__restrict__ out) {
+    P2_WALK_PROLOGUE
+    float *Tq = lds, *Tk = lds + tsz;
+    stage_table<D>(Tq, table_q, L, h, h0, hgn);
+    stage_table<D>(Tk, table_k, L, h, h0, hgn);
+    __syncthreads();
+    for (int qi = blockIdx.x * 4 + wave; qi < N; qi += gridDim.x * 4) {
+        float4 q4[HG];
+#pragma unroll
+        for (int t = 0; t < HG; t++)
+            q4[t] = t < hgn ? ldg4(q + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
+        const int s = offs[qi], e = offs[qi + 1];
+        for (int m0 = s; m0 < e; m0 += PPW) {
+            const int m = m0 + p;
+            const bool valid = m < e;
+            const int mm = valid ? m : s;
+            const int j = idx_k[mm];
+            const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+            float keep = 0.f;
+#pragma unroll
+            for (int t = 0; t < HG; t++) {
+                if (t < hgn) {
+                    const float4 k4 = ldg4(k + (size_t)j * C + (h0 + t) * D + 4 * c);
+                    float part = dot4(q4[t], tsum<D>(Tq, L, t, r0, r1, r2, c)) + dot4(k4, tsum<D>(Tk, L, t, r0, r1, r2, c));
+                    float tot = xor_sum<1, LPG>(part);
+                    if (c == t) keep = tot;
+                }
+            }
+            if (valid && c < hgn) out[(size_t)m * h + h0 + c] = keep;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2 backward, by query: grad_q (stored), grad_table_q (LDS -> atomics).
+// KEYSIDE: also grad_k (global atomics) and grad_table_k — the no-CSC fallback.
+// ------------------------------------------------------------------------------------------------
+template <int D, int HG, bool KEYSIDE>
+__global__ __launch_bounds__(256) void a2_bwd_query_kernel(int N, int h, int L, const float *__restrict__ go,
+                                                           const float *__restrict__ q, const int *__restrict__ offs,
+                                                           const float *__restrict__ k, const int *__restrict__ idx_k,
+                                                           const float *__restrict__ table_q, const float *__restrict__ table_k,
+                                                           const int *__restrict__ rel, float *__restrict__ grad_q,
+                                                           float *__restrict__ grad_k, float *__restrict__ grad_table_q,
+                                                           float *__restrict__ grad_table_k) {
+    P2_WALK_PROLOGUE
+    float *Tq = lds, *Gq = lds + tsz, *Tk = lds + 2 * tsz, *Gk = lds + 3 * tsz;
+    stage_table<D>(Tq, table_q, L, h, h0, hgn);
+    zero_lds<D>(Gq, tsz);
+    if (KEYSIDE) {
+        stage_table<D>(Tk, table_k, L, h, h0, hgn);
+        zero_lds<D>(Gk, tsz);
+    }
+    __syncthreads();
+    for (int qi = blockIdx.x * 4 + wave; qi < N; qi += gridDim.x * 4) {
+        float4 q4[HG], acc[HG];
+#pragma unroll
+        for (int t = 0; t < HG; t++) {
+            q4[t] = t < hgn ? ldg4(q + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
+            acc[t] = make_float4(0, 0, 0, 0);
+        }
+        const int s = offs[qi], e = offs[qi + 1];
+        for (int m0 = s; m0 < e; m0 += PPW) {
+            const int m = m0 + p;
+            if (m < e) {
+                const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
+                const int j = KEYSIDE ? idx_k[m] : 0;
+#pragma unroll
+                for (int t = 0; t < HG; t++) {
+                    if (t < hgn) {
+                        const float g = go[(size_t)m * h + h0 + t];
+                        acc[t] = fma4(g, tsum<D>(Tq, L, t, r0, r1, r2, c), acc[t]);
+                        tadd<D>(Gq, L, t, r0, r1, r2, c, scale4(g, q4[t]));
+                        if (KEYSIDE) {
+                            float *kp = (float *)k + (size_t)j * C + (h0 + t) * D + 4 * c;
+                            const float4 k4 = ldg4(kp);
+                            const float4 gk = scale4(g, tsum<D>(Tk, L, t, r0, r1, r2, c));
+                            float *d = grad_k + (size_t)j * C + (h0 + t) * D + 4 * c;
+                            atomicAdd(d + 0, gk.x); atomicAdd(d + 1, gk.y); atomicAdd(d + 2, gk.z); atomicAdd(d + 3, gk.w);
+                            tadd<D>(Gk, L, t, r0, r1, r2, c, scale4(g, k4));
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HG; t++) {
+            if (t < hgn) {
+                float4 tot = xor_sum4<LPG, 64>(acc[t]);
+                if (p == 0) stg4(grad_q + (size_t)qi * C + (h0 + t) * D + 4 * c, tot);
+            }
+        }
+    }
+    __syncthreads();
+    flush_table<D>(Gq, grad_table_q, L, h, h0, hgn);
+    if (KEYSIDE) flush_table<D>(Gk, grad_table_k, L, h, h0, hgn);
+}
+
+// A2 backward, by key (CSC): grad_k (accumulated into the pre-zeroed buffer), grad_table_k.
+template <int D, int HG>
+__global__ __launch_bounds__(256) void a2_bwd_key_kernel(int N, int h, int L, const float *__restrict__ go,
+                                                         const float *__restrict__ k, const int *__restrict__ csc_offs,
+                                                         const int *__restrict__ csc_pair, const float *__restrict__ table_k,
+                                                         const int *__restrict__ rel, float *__restrict__ grad_k,
+                                                         float *__restrict__ grad_table_k) {
+    P2_WALK_PROLOGUE
+    float *Tk = lds, *Gk = lds + tsz;
+    stage_table<D>(Tk, table_k, L, h, h0, hgn);
+    zero_lds<D>(Gk, tsz);
+    __syncthreads();
+    for (int kj = blockIdx.x * 4 + wave; kj < N; kj += gridDim.x * 4) {
+        float4 k4[HG], acc[HG];
+#pragma unroll
+        for (int t = 0; t < HG; t++) {
+            k4[t] = t < hgn ? ldg4(k + (size_t)kj * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
+            acc[t] = make_float4(0, 0, 0, 0);
+        }
+        const int s = csc_offs[kj], e = csc_offs[kj + 1];
+        for (int m0 = s; m0 < e; m0 += PPW) {
+            const int slot = m0 + p;
+            if (slot < e) {
+                const int m = csc_pair[slot];
+                const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
+#pragma unroll
+                for (int t = 0; t < HG; t++) {
+                    if (t < hgn) {
+                        const float g = go[(size_t)m * h + h0 + t];
+                        acc[t] = fma4(g, tsum<D>(Tk, L, t, r0, r1, r2, c), acc[t]);
+                        tadd<D>(Gk, L, t, r0, r1, r2, c, scale4(g, k4[t]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HG; t++) {
+            if (t < hgn) {
+                float4 tot = xor_sum4<LPG, 64>(acc[t]);
+                if (p == 0) {
+                    float *o = grad_k + (size_t)kj * C + (h0 + t) * D + 4 * c;
+                    stg4(o, add4(tot, ldg4(o)));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    flush_table<D>(Gk, grad_table_k, L, h, h0, hgn);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A4 forward: out[q,hh,:] = sum_m attn[m,hh] * (v[idx1[m],hh,:] + Tv(m,hh,:))
+// ------------------------------------------------------------------------------------------------
+template <int D, int HG>
+__global__ __launch_bounds__(256) void a4_fwd_kernel(int N, int h, int L, const float *__restrict__ attn,
+                                                     const float *__restrict__ v, const int *__restrict__ offs,
+                                                     const int *__restrict__ idx1, const float *__restrict__ table,
+                                                     const int *__restrict__ rel, float *__restrict__ out) {
+    P2_WALK_PROLOGUE
+    float *Tv = lds;
+    stage_table<D>(Tv, table, L, h, h0, hgn);
+    __syncthreads();
+    for (int qi = blockIdx.x * 4 + wave; qi < N; qi += gridDim.x * 4) {
+        float4 acc[HG];
+#pragma unroll
+        for (int t = 0; t < HG; t++) acc[t] = make_float4(0, 0, 0, 0);
+        const int s = offs[qi], e = offs[qi + 1];
+        for (int m0 = s; m0 < e; m0 += PPW) {
+            const int m = m0 + p;
+            if (m < e) {
+                const int j = idx1[m];
+                const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
+#pragma unroll
+                for (int t = 0; t < HG; t++) {
+                    if (t < hgn) {
+                        const float a = attn[(size_t)m * h + h0 + t];
+                        const float4 v4 = ldg4(v + (size_t)j * C + (h0 + t) * D + 4 * c);
+                        acc[t] = fma4(a, add4(tsum<D>(Tv, L, t, r0, r1, r2, c), v4), acc[t]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HG; t++) {
+            if (t < hgn) {
+                float4 tot = xor_sum4<LPG, 64>(acc[t]);
+                if (p == 0) stg4(out + (size_t)qi * C + (h0 + t) * D + 4 * c, tot);
+            }
+        }
+    }
+}
+
+// A4 backward, by query: grad_attn (stored), grad_table (LDS -> atomics); KEYSIDE: grad_v by atomics.
+template <int D, int HG, bool KEYSIDE>
+__global__ __launch_bounds__(256) void a4_bwd_query_kernel(int N, int h, int L, const float *__restrict__ go,
+                                                           const int *__restrict__ offs, const int *__restrict__ idx1,
+                                                           const float *__restrict__ attn, const float *__restrict__ v,
+                                                           const float *__restrict__ table, const int *__restrict__ rel,
+                                                           float *__restrict__ grad_attn, float *__restrict__ grad_v,
+                                                           float *__restrict__ grad_table) {
+    P2_WALK_PROLOGUE
+    float *Tv = lds, *Gv = lds + tsz;
+    stage_table<D>(Tv, table, L, h, h0, hgn);
+    zero_lds<D>(Gv, tsz);
+    __syncthreads();
+    for (int qi = blockIdx.x * 4 + wave; qi < N; qi += gridDim.x * 4) {
+        float4 g4[HG];
+#pragma unroll
+        for (int t = 0; t < HG; t++)
+            g4[t] = t < hgn ? ldg4(go + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
+        const int s = offs[qi], e = offs[qi + 1];
+        for (int m0 = s; m0 < e; m0 += PPW) {
+            const int m = m0 + p;
+            const bool valid = m < e;
+            const int mm = valid ? m : s;
+            const int j = idx1[mm];
+            const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+            float keep = 0.f;
+#pragma unroll
+            for (int t = 0; t < HG; t++) {
+                if (t < hgn) {
+                    const float4 v4 = ldg4(v + (size_t)j * C + (h0 + t) * D + 4 * c);
+                    float part = dot4(add4(tsum<D>(Tv, L, t, r0, r1, r2, c), v4), g4[t]);
+                    float tot = xor_sum<1, LPG>(part);
+                    if (c == t) keep = tot;
+                    if (valid) {
+                        const float a = attn[(size_t)m * h + h0 + t];
+                        const float4 ag = scale4(a, g4[t]);
+                        tadd<D>(Gv, L, t, r0, r1, r2, c, ag);
+                        if (KEYSIDE) {
+                            float *d = grad_v + (size_t)j * C + (h0 + t) * D + 4 * c;
+                            atomicAdd(d + 0, ag.x); atomicAdd(d + 1, ag.y); atomicAdd(d + 2, ag.z); atomicAdd(d + 3, ag.w);
+                        }
+                    }
+                }
+            }
+            if (valid && c < hgn) grad_attn[(size_t)m * h + h0 + c] = keep;
+        }
+    }
+    __syncthreads();
+    flush_table<D>(Gv, grad_table, L, h, h0, hgn);
+}
+
+// key-major accumulate used for grad_v (defined in attention.hip, instantiated here through a thin
+// duplicate to keep the translation units independent)
+template <int D>
+__global__ __launch_bounds__(256) void key_accum_kernel(int N, int h, const int *__restrict__ offs,
+                                                        const int *__restrict__ sidx, const int *__restrict__ widx,
+                                                        const float *__restrict__ w, const float *__restrict__ src,
+                                                        float *__restrict__ out) {
+    constexpr int LPG = Geo<D>::LPG, PPW = Geo<D>::PPW, HC = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= N) return;
+    const int C = h * D;
+    const int p = lane / LPG, c = lane % LPG;
+    const int s = offs[row], e = offs[row + 1];
+    for (int hb = 0; hb < h; hb += HC) {
+        float4 acc[HC];
+#pragma unroll
+        for (int t = 0; t < HC; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int m0 = s; m0 < e; m0 += PPW) {
+            const int slot = m0 + p;
+            if (slot < e) {
+                const float *srow = src + (size_t)sidx[slot] * C + 4 * c;
+                const float *wrow = w + (size_t)widx[slot] * h;
+#pragma unroll
+                for (int t = 0; t < HC; t++)
+                    if (hb + t < h) acc[t] = fma4(wrow[hb + t], ldg4(srow + (hb + t) * D), acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HC; t++) {
+            if (hb + t < h) {
+                float4 tot = xor_sum4<LPG, 64>(acc[t]);
+                if (p == 0) {
+                    float *o = out + (size_t)row * C + (hb + t) * D + 4 * c;
+                    stg4(o, add4(tot, ldg4(o)));
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v1 pair-indexed forms (relative_pos_encoding_cuda_kernel.cu:7-136): one thread per (pair, head),
+// atomics where the reference has them.  Tables are read from global memory (L is not needed).
+// ------------------------------------------------------------------------------------------------
+__global__ void dot_v1_fwd_kernel(int M, int h, int d, const float *q, const int *index, const float *table,
+                                  const int *rel, float *out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * h) return;
+    const int m = t / h, hh = t % h;
+    const float *qv = q + ((size_t)index[m] * h + hh) * d;
+    float sum = 0.f;
+    for (int ax = 0; ax < 3; ax++) {
+        const float *tb = table + (((size_t)rel[m * 3 + ax] * h + hh) * d) * 3 + ax;
+        for (int i = 0; i < d; i++) sum = fmaf(qv[i], tb[i * 3], sum);
+    }
+    out[t] += sum;
+}
+__global__ void dot_v1_bwd_kernel(int M, int h, int d, const float *go, const float *q, const int *index,
+                                  const float *table, const int *rel, float *gq, float *gt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * h) return;
+    const int m = t / h, hh = t % h;
+    const size_t qb = ((size_t)index[m] * h + hh) * d;
+    const float g = go[t];
+    for (int ax = 0; ax < 3; ax++) {
+        const size_t tb = (((size_t)rel[m * 3 + ax] * h + hh) * d) * 3 + ax;
+        for (int i = 0; i < d; i++) {
+            atomicAdd(gq + qb + i, g * table[tb + i * 3]);
+            atomicAdd(gt + tb + i * 3, g * q[qb + i]);
+        }
+    }
+}
+__global__ void av_v1_fwd_kernel(int M, int h, int d, const float *attn, const float *v, const int *i0, const int *i1,
+                                 const float *table, const int *rel, float *out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * h) return;
+    const int m = t / h, hh = t % h;
+    const size_t ob = ((size_t)i0[m] * h + hh) * d, vb = ((size_t)i1[m] * h + hh) * d;
+    const float a = attn[t];
+    const float *t0 = table + (((size_t)rel[m * 3 + 0] * h + hh) * d) * 3 + 0;
+    const float *t1 = table + (((size_t)rel[m * 3 + 1] * h + hh) * d) * 3 + 1;
+    const float *t2 = table + (((size_t)rel[m * 3 + 2] * h + hh) * d) * 3 + 2;
+    for (int i = 0; i < d; i++) atomicAdd(out + ob + i, a * (v[vb + i] + (t0[i * 3] + t1[i * 3] + t2[i * 3])));
+}
+__global__ void av_v1_bwd_kernel(int M, int h, int d, const float *go, const int *i0, const int *i1, const float *attn,
+                                 const float *v, const float *table, const int *rel, float *ga, float *gv, float *gt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * h) return;
+    const int m = t / h, hh = t % h;
+    const size_t ob = ((size_t)i0[m] * h + hh) * d, vb = ((size_t)i1[m] * h + hh) * d;
+    const float a = attn[t];
+    const size_t b0 = (((size_t)rel[m * 3 + 0] * h + hh) * d) * 3 + 0;
+    const size_t b1 = (((size_t)rel[m * 3 + 1] * h + hh) * d) * 3 + 1;
+    const size_t b2 = (((size_t)rel[m * 3 + 2] * h + hh) * d) * 3 + 2;
+    float sum = 0.f;
+    for (int i = 0; i < d; i++) {
+        const float g = go[ob + i];
+        sum = fmaf(g, v[vb + i] + (table[b0 + i * 3] + table[b1 + i * 3] + table[b2 + i * 3]), sum);
+        atomicAdd(gv + vb + i, g * a);
+        atomicAdd(gt + b0 + i * 3, g * a);
+        atomicAdd(gt + b1 + i * 3, g * a);
+        atomicAdd(gt + b2 + i * 3, g * a);
+    }
+    ga[t] += sum;
+}
+
+// chooses heads-per-workgroup so that `narr` table images fit the LDS budget
+static int pick_hg(int h, int L, int D, int narr) {
+    const size_t per_head = (size_t)narr * 3 * L * D * sizeof(float);
+    int hg = (int)(kLdsBudget / per_head);
+    if (hg < 1) {
+        if (per_head <= 150 * 1024) return 1;  // one workgroup per CU
+        return 0;
+    }
+    if (hg > 3) hg = 3;
+    if (hg > h) hg = h;
+    return hg;
+}
+
+static int table_rows_or_error() {
+    const int L = state().table_rows;
+    if (L <= 0) set_error("rel-pos tables: call pointops2_set_table_rows(L) before this launcher");
+    return L;
+}
+
+static int persistent_blocks(int rows, int head_groups) {
+    int want = div_up(rows, 4);
+    int cap = kNumCU * 2;  // 72 KB LDS => two workgroups per CU
+    if (head_groups > 1) cap = max(kNumCU * 2 / head_groups, kNumCU / 2);
+    return min(want, cap);
+}
+
+template <int D, typename F>
+static void with_hg(int hg, F f) {
+    if (hg == 1) f(std::integral_constant<int, 1>{});
+    else if (hg == 2) f(std::integral_constant<int, 2>{});
+    else f(std::integral_constant<int, 3>{});
+}
+
+}  // namespace p2
+
+using namespace p2;
+
+#define P2_LAUNCH_HG(D_, narr_, BODY)                                                           \
+    {                                                                                           \
+        const int hg = pick_hg(h, L, D_, narr_);                                                \
+        if (hg == 0) { set_error("rel-pos table slice does not fit in LDS"); return; }          \
+        const int ngroups = div_up(h, hg);                                                      \
+        const size_t lds_bytes = (size_t)narr_ * hg * 3 * L * D_ * sizeof(float);               \
+        with_hg<D_>(hg, [&](auto hgtag) {                                                       \
+            constexpr int HGc = decltype(hgtag)::value;                                         \
+            constexpr int Dc = D_;                                                              \
+            (void)HGc; (void)Dc;                                                                \
+            BODY                                                                                \
+        });                                                                                     \
+        (void)ngroups; (void)lds_bytes;                                                         \
+    }
+
+extern "C" {
+
+void dot_prod_with_idx_forward_cuda_launcher_v3(int N, int M, int h, int hdim, int n_max, const float *q,
+                                                const int *index_q_offsets, const float *k, const int *index_k,
+                                                const float *table_q, const float *table_k, const int *rel_idx,
+                                                float *output) {
+    (void)n_max;
+    if (N <= 0 || M <= 0) return;
+    const int L = table_rows_or_error();
+    if (L <= 0) return;
+    hipStream_t st = state().stream;
+    if (hdim == 16) P2_LAUNCH_HG(16, 2, {
+        allow_big_lds(a2_fwd_kernel<Dc, HGc>, lds_bytes);
+        hipLaunchKernelGGL((a2_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), lds_bytes, st,
+                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output);
+    })
+    else if (hdim == 32) P2_LAUNCH_HG(32, 2, {
+        allow_big_lds(a2_fwd_kernel<Dc, HGc>, lds_bytes);
+        hipLaunchKernelGGL((a2_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), lds_bytes, st,
+                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output);
+    })
+    else { set_error("d != 16 and d != 32"); return; }
+    check_launch();
+}
+
+void dot_prod_with_idx_backward_cuda_launcher_v3(int N, int M, int h, int hdim, int n_max, const float *grad_out,
+                                                 const float *q, const int *index_q_offsets, const float *k,
+                                                 const int *index_k, const float *table_q, const float *table_k,
+                                                 const int *rel_idx, float *grad_q, float *grad_k,
+                                                 float *grad_table_q, float *grad_table_k) {
+    (void)n_max;
+    if (N <= 0 || M <= 0) return;
+    const int L = table_rows_or_error();
+    if (L <= 0) return;
+    hipStream_t st = state().stream;
+    const LaunchState &ls = state();
+    const int *co = ls.csc_offsets, *cp = ls.csc_pair;
+#define P2_A2_BWD(D_)                                                                                                       \
+    if (co) {                                                                                                               \
+        P2_LAUNCH_HG(D_, 2, {                                                                                               \
+            allow_big_lds(a2_bwd_query_kernel<Dc, HGc, false>, lds_bytes);                                                  \
+            allow_big_lds(a2_bwd_key_kernel<Dc, HGc>, lds_bytes);                                                           \
+            hipLaunchKernelGGL((a2_bwd_query_kernel<Dc, HGc, false>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \
+                               lds_bytes, st, N, h, L, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx,  \
+                               grad_q, grad_k, grad_table_q, grad_table_k);                                                 \
+            hipLaunchKernelGGL((a2_bwd_key_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256),        \
+                               lds_bytes, st, N, h, L, grad_out, k, co, cp, table_k, rel_idx, grad_k, grad_table_k);        \
+        })                                                                                                                  \
+    } else {                                                                                                                \
+        P2_LAUNCH_HG(D_, 4, {                                                                                               \
+            allow_big_lds(a2_bwd_query_kernel<Dc, HGc, true>, lds_bytes);                                                   \
+            hipLaunchKernelGGL((a2_bwd_query_kernel<Dc, HGc, true>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \
+                               lds_bytes, st, N, h, L, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx,  \
+                               grad_q, grad_k, grad_table_q, grad_table_k);                                                 \
+        })                                                                                                                  \
+    }
+    if (hdim == 16) { P2_A2_BWD(16) }
+    else if (hdim == 32) { P2_A2_BWD(32) }
+    else { set_error("d != 16 and d != 32"); return; }
+#undef P2_A2_BWD
+    check_launch();
+}
+
+void attention_step2_with_rel_pos_value_forward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max,
+                                                                 const float *attn, const float *v,
+                                                                 const int *index0_offsets, const int *index1,
+                                                                 const float *table, const int *rel_idx, float *output) {
+    (void)n_max;
+    if (N <= 0 || M <= 0) return;
+    const int L = table_rows_or_error();
+    if (L <= 0) return;
+    hipStream_t st = state().stream;
+    if (hdim == 16) P2_LAUNCH_HG(16, 1, {
+        allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
+        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), lds_bytes, st,
+                           N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output);
+    })
+    else if (hdim == 32) P2_LAUNCH_HG(32, 1, {
+        allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
+        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), lds_bytes, st,
+                           N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output);
+    })
+    else { set_error("d != 16 and d != 32"); return; }
+    check_launch();
+}
+
+void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max,
+                                                                  const float *grad_out, const int *index0_offsets,
+                                                                  const int *index1, const float *attn, const float *v,
+                                                                  const float *table, const int *rel_idx,
+                                                                  float *grad_attn, float *grad_v, float *grad_table) {
+    (void)n_max;
+    if (N <= 0 || M <= 0) return;
+    const int L = table_rows_or_error();
+    if (L <= 0) return;
+    hipStream_t st = state().stream;
+    const LaunchState &ls = state();
+    const int *co = ls.csc_offsets, *cp = ls.csc_pair, *cq = ls.csc_query;
+#define P2_A4_BWD(D_)                                                                                                       \
+    P2_LAUNCH_HG(D_, 2, {                                                                                                   \
+        allow_big_lds(a4_bwd_query_kernel<Dc, HGc, false>, lds_bytes);                                                      \
+        allow_big_lds(a4_bwd_query_kernel<Dc, HGc, true>, lds_bytes);                                                       \
+        if (co) {                                                                                                           \
+            hipLaunchKernelGGL((a4_bwd_query_kernel<Dc, HGc, false>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \
+                               lds_bytes, st, N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, \
+                               grad_v, grad_table);                                                                         \
+            hipLaunchKernelGGL(key_accum_kernel<Dc>, dim3(div_up(N, 4)), dim3(256), 0, st, N, h, co, cq, cp, attn, grad_out, \
+                               grad_v);                                                                                     \
+        } else {                                                                                                            \
+            hipLaunchKernelGGL((a4_bwd_query_kernel<Dc, HGc, true>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \
+                               lds_bytes, st, N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, \
+                               grad_v, grad_table);                                                                         \
+        }                                                                                                                   \
+    })
+    if (hdim == 16) { P2_A4_BWD(16) }
+    else if (hdim == 32) { P2_A4_BWD(32) }
+    else { set_error("d != 16 and d != 32"); return; }
+#undef P2_A4_BWD
+    check_launch();
+}
+
+// ---- v1 forms ----
+void dot_prod_with_idx_forward_cuda_launcher(int N, int M, int h, int hdim, const float *q, const int *index,
+                                             const float *table, const int *rel_idx, float *output) {
+    (void)N;
+    if (M <= 0) return;
+    hipLaunchKernelGGL(dot_v1_fwd_kernel, dim3(div_up64((int64_t)M * h, 256)), dim3(256), 0, state().stream, M, h, hdim, q, index, table, rel_idx, output);
+    check_launch();
+}
+void dot_prod_with_idx_backward_cuda_launcher(int N, int M, int h, int hdim, const float *grad_out,
+                                              const float *q, const int *index, const float *table,
+                                              const int *rel_idx, float *grad_q, float *grad_table) {
+    (void)N;
+    if (M <= 0) return;
+    hipLaunchKernelGGL(dot_v1_bwd_kernel, dim3(div_up64((int64_t)M * h, 256)), dim3(256), 0, state().stream, M, h, hdim, grad_out, q, index, table, rel_idx, grad_q, grad_table);
+    check_launch();
+}
+void attention_step2_with_rel_pos_value_forward_cuda_launcher(int N, int M, int h, int hdim, const float *attn,
+                                                              const float *v, const int *index0, const int *index1,
+                                                              const float *table, const int *rel_idx, float *output) {
+    (void)N;
+    if (M <= 0) return;
+    hipLaunchKernelGGL(av_v1_fwd_kernel, dim3(div_up64((int64_t)M * h, 256)), dim3(256), 0, state().stream, M, h, hdim, attn, v, index0, index1, table, rel_idx, output);
+    check_launch();
+}
+void attention_step2_with_rel_pos_value_backward_cuda_launcher(int N, int M, int h, int hdim, const float *grad_out,
+                                                               const int *index0, const int *index1, const float *attn,
+                                                               const float *v, const float *table, const int *rel_idx,
+                                                               float *grad_attn, float *grad_v, float *grad_table) {
+    (void)N;
+    if (M <= 0) return;
+    hipLaunchKernelGGL(av_v1_bwd_kernel, dim3(div_up64((int64_t)M * h, 256)), dim3(256), 0, state().stream, M, h, hdim, grad_out, index0, index1, attn, v, table, rel_idx, grad_attn, grad_v, grad_table);
+    check_launch();
+}
+
+// The bucketed "v2" bias (relative_pos_encoding_cuda_kernel_v2.cu:9-243) computes the same function
+// as v3; its extra arguments (T, rel_idx_offsets, sort_indices: pairs bucketed by merged rel index)
+// only drive the reference's work distribution.  index_q/index_k are pair-indexed (unsorted), so it
+// is served by two passes of the v1 single-table kernel (q-side + k-side), which is exactly the
+// identity the reference's own test checks (test_relative_pos_encoding_op_step1_v3.py:60-62).
+void dot_prod_with_idx_forward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max, int T, const float *q,
+                                                const int *index_q, const float *k, const int *index_k,
+                                                const float *table_q, const float *table_k, const int *rel_idx,
+                                                const int *rel_idx_offsets, const int *sort_indices, float *output) {
+    (void)n_max; (void)T; (void)rel_idx_offsets; (void)sort_indices;
+    dot_prod_with_idx_forward_cuda_launcher(N, M, h, hdim, q, index_q, table_q, rel_idx, output);
+    dot_prod_with_idx_forward_cuda_launcher(N, M, h, hdim, k, index_k, table_k, rel_idx, output);
+}
+void dot_prod_with_idx_backward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max, int T, const float *grad_out,
+                                                 const float *q, const int *index_q, const float *k, const int *index_k,
+                                                 const float *table_q, const float *table_k, const int *rel_idx,
+                                                 const int *rel_idx_offsets, const int *sort_indices, float *grad_q,
+                                                 float *grad_k, float *grad_table_q, float *grad_table_k) {
+    (void)n_max; (void)T; (void)rel_idx_offsets; (void)sort_indices;
+    dot_prod_with_idx_backward_cuda_launcher(N, M, h, hdim, grad_out, q, index_q, table_q, rel_idx, grad_q, grad_table_q);
+    dot_prod_with_idx_backward_cuda_launcher(N, M, h, hdim, grad_out, k, index_k, table_k, rel_idx, grad_k, grad_table_k);
+}
+
+}  // extern "C"

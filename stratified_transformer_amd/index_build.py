@@ -1,0 +1,169 @@
+"""On-device index build for one Stratified Transformer stage.
+
+Produces, bit-identically to the reference's model code in its canonical (stable-sort) order, what
+`BasicLayer.forward` / `WindowAttention.forward` compute with `[nW,k,k]` boolean masks, a 12 M-element
+sort per block and four host syncs (model/stratified_transformer.py:10-65, 186-190, 271-317):
+
+    window partition (grid_sample)   -> per-point window ids, window-sorted point lists
+    pair list (get_indice_pairs+CSR) -> index_1 [M] i32, index_0_offsets [N+1] i32 (+ index_0, n_max)
+    relative-position index          -> rel_idx [M,3] i32
+
+Algorithm (O(M), no masks, no pair sort): points are bucketed by window id with one stable sort per
+partition; a query's dense keys are its small window's bucket, its stratified keys the sampled points
+of its large window's bucket whose small-window coordinate differs from the query's; both lists are
+already ascending by point index, so the CSR is written directly at prefix-summed offsets.
+
+This module is the host-side orchestration.  It runs on whatever device the inputs live on (the
+tests compare it with the oracle on CPU); on the GPU the heavy steps dispatch to HIP kernels when
+`use_hip=True` (stratified_transformer_amd/csrc/index.hip).
+"""
+from dataclasses import dataclass
+
+import torch
+
+RECIP_1E5 = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(100000.0, dtype=torch.float32)
+
+
+@dataclass
+class WindowPartition:
+    """One grid_sample() result in segment form."""
+    cluster: torch.Tensor      # [N] i64   dense window id per point (rank of the voxel id)
+    order: torch.Tensor        # [N] i64   point ids sorted by (window, point id)
+    starts: torch.Tensor       # [nW+1] i64 bucket boundaries into `order`
+    n_windows: int
+
+
+@dataclass
+class BlockIndex:
+    index_0: torch.Tensor          # [M] i32 (ascending)
+    index_1: torch.Tensor          # [M] i32
+    offsets: torch.Tensor          # [N+1] i32
+    n_max: torch.Tensor            # 0-dim i64 on device, like the model's (:315)
+    rel_idx: torch.Tensor          # [M,3] i32
+    n_dense: torch.Tensor          # [N] i64 dense keys per query (diagnostics)
+
+
+def batch_ids(offset, n):
+    """:273-275 without the Python list comprehension: batch id per point from cumulative offsets."""
+    offset = offset.to(torch.int64)
+    return torch.searchsorted(offset, torch.arange(n, device=offset.device), right=True)
+
+
+def voxel_ids(pos, batch, size, start):
+    """torch_geometric 1.7.0 voxel_grid -> torch_cluster grid_cluster arithmetic (see compat.voxel_grid)."""
+    from .compat import voxel_grid
+    return voxel_grid(pos, batch, size, start=start)
+
+
+def partition(pos, batch, size, start):
+    """grid_sample (:44-65) in segment form; `order`/`starts` replace the zero-padded p2v_map/counts."""
+    vid = voxel_ids(pos, batch, size, start)
+    uniq, cluster, counts = torch.unique(vid, sorted=True, return_inverse=True, return_counts=True)
+    order = torch.argsort(cluster, stable=True)
+    starts = torch.zeros(counts.shape[0] + 1, dtype=torch.int64, device=pos.device)
+    starts[1:] = counts.cumsum(0)
+    return WindowPartition(cluster, order, starts, int(uniq.shape[0]))
+
+
+def p2v_map(part):
+    """Materialises the reference's zero-padded p2v_map/counts from a partition (tests only)."""
+    counts = part.starts[1:] - part.starts[:-1]
+    k = int(counts.max())
+    out = torch.zeros(part.n_windows, k, dtype=torch.int64, device=counts.device)
+    mask = torch.arange(k, device=counts.device).unsqueeze(0) < counts.unsqueeze(-1)
+    out[mask] = part.order
+    return out, counts
+
+
+def window_coord(xyz, window_size, shifted):
+    """:28-32 fp32 floor-division coordinate used by the stratified mask."""
+    ws = torch.tensor([window_size] * 3).type_as(xyz)
+    xyz_min = xyz.min(0)[0]
+    if not shifted:
+        return (xyz - xyz_min) // ws
+    return (xyz + 1 / 2 * ws - xyz_min) // ws
+
+
+def rel_pos_index(xyz, index_0, index_1, window_size, quant_size):
+    """:186-188 with the GPU's arithmetic for `/ 100000` (ATen multiplies by the fp32 reciprocal when a
+    CUDA/HIP tensor is divided by a Python scalar); evaluated identically on any device."""
+    rel = xyz[index_0.long()] - xyz[index_1.long()]
+    rel = torch.round(rel * 100000) * RECIP_1E5.to(xyz.device)
+    return ((rel + 2 * window_size - 0.0001) // quant_size).int()
+
+
+def _expand(counts):
+    """row id and position-within-row for a ragged layout with `counts` entries per row."""
+    rows = torch.repeat_interleave(torch.arange(counts.shape[0], device=counts.device), counts)
+    starts = counts.cumsum(0) - counts
+    local = torch.arange(rows.shape[0], device=counts.device) - starts[rows]
+    return rows, local
+
+
+def build_block_index(xyz, small, large, downsample_idx, window_size, quant_size, shifted):
+    """Pair list + rel-pos index of one block (even block: shifted=False, odd: True).
+
+    small / large: WindowPartition of the (shifted) small / 2x windows; downsample_idx [m] i32 = FPS subset.
+    """
+    N, dev = xyz.shape[0], xyz.device
+    # dense keys: the whole bucket of the query's small window (ascending point id inside a bucket)
+    s_cnt = (small.starts[1:] - small.starts[:-1])
+    n_dense = s_cnt[small.cluster]
+    # stratified candidates: sampled points bucketed by large window
+    sampled = torch.zeros(N, dtype=torch.bool, device=dev)
+    sampled[downsample_idx.long()] = True
+    l_sorted_sampled = large.order[sampled[large.order]]                 # sampled point ids, (window, id) order
+    l_cnt = torch.bincount(large.cluster[l_sorted_sampled], minlength=large.n_windows)
+    l_starts = l_cnt.cumsum(0) - l_cnt
+    cand_cnt = l_cnt[large.cluster]
+    q, local = _expand(cand_cnt)
+    cand = l_sorted_sampled[l_starts[large.cluster[q]] + local]
+    wc = window_coord(xyz, window_size, shifted)
+    keep = (wc[q] != wc[cand]).any(-1)
+    sq, sk = q[keep], cand[keep]
+    n_strat = torch.bincount(sq, minlength=N)
+    total = n_dense + n_strat
+    offsets = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = total.cumsum(0)
+    M = int(offsets[-1])
+    index_1 = torch.empty(M, dtype=torch.int64, device=dev)
+    dq, dl = _expand(n_dense)
+    index_1[offsets[dq] + dl] = small.order[small.starts[small.cluster[dq]] + dl]
+    s_local = torch.arange(sq.shape[0], device=dev) - (n_strat.cumsum(0) - n_strat)[sq]
+    index_1[offsets[sq] + n_dense[sq] + s_local] = sk
+    index_0 = torch.repeat_interleave(torch.arange(N, device=dev), total)
+    rel = rel_pos_index(xyz, index_0, index_1, window_size, quant_size)
+    return BlockIndex(index_0.int(), index_1.int(), offsets.int(), total.max(), rel, n_dense)
+
+
+def stratified_new_offset(offset, downsample_scale):
+    """:283-288 on host integers"""
+    offs = [int(o) for o in offset]
+    out, count = [offs[0] // downsample_scale + 1], offs[0] // downsample_scale + 1
+    for i in range(1, len(offs)):
+        count += (offs[i] - offs[i - 1]) // downsample_scale + 1
+        out.append(count)
+    return out
+
+
+def transition_down_offset(offset, ratio):
+    """:98-102 (float accumulation for b>0, truncated at the end by IntTensor)"""
+    offs = [int(o) for o in offset]
+    out, count = [int(offs[0] * ratio) + 1], int(offs[0] * ratio) + 1
+    for i in range(1, len(offs)):
+        count += ((offs[i] - offs[i - 1]) * ratio) + 1
+        out.append(count)
+    return [int(c) for c in out]
+
+
+def stage_partitions(xyz, offset, window_size):
+    """The four grid_sample calls of BasicLayer.forward (:277,280,297,300)."""
+    batch = batch_ids(offset, xyz.shape[0])
+    ws = torch.tensor([window_size] * 3).type_as(xyz)
+    xyz_min = xyz.min(0)[0]
+    return {
+        "small": partition(xyz, batch, ws, None),
+        "small_shift": partition(xyz + 1 / 2 * ws, batch, ws, xyz_min),
+        "large": partition(xyz, batch, 2 * ws, None),
+        "large_shift": partition(xyz + 1 / 2 * (2 * ws), batch, 2 * ws, xyz_min),
+    }

@@ -1,0 +1,585 @@
+"""Operator API of the Stratified Transformer hot path on MI355X.
+
+Drop-in for the reference's `lib/pointops2/functions/pointops.py` (SURVEY.md §8b seam B1): the same
+module-level callables, positional arguments, return shapes/dtypes and `backward` arities, written
+from scratch over the C ABI of libpointops2_hip.so (through `pointops2_cuda`).  Citations are to
+/root/reference/lib/pointops2/functions/pointops.py.
+
+Differences, all compatible:
+  * `n_max` may be an int or the 0-dim device tensor the model passes
+    (model/stratified_transformer.py:315); it is never read on the host (no device sync) because
+    the kernels do not size their workgroups by it and have no 1024-keys-per-query limit
+    (the reference asserts `n_max <= 1024`, :150).
+  * Backward passes do not scatter with global float atomics: a key-major (CSC) transposition of
+    the pair list is built once per index pattern (cached, keyed by tensor identity) and the
+    key-side gradients are gathered.
+  * Inputs must be GPU tensors: there is no CPU fallback.
+"""
+from collections import OrderedDict
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from . import pointops2_cuda as pointops_cuda
+from ._lib import ptr
+
+
+def _zeros(shape, ref, dtype=torch.float32):
+    return torch.zeros(shape, dtype=dtype, device=ref.device)
+
+
+def _nmax(n_max):
+    return n_max if isinstance(n_max, int) else 0
+
+
+# ---------------------------------------------------------------------------------------------
+# key-major (CSC) view of a CSR pair list, shared by the backward kernels
+# ---------------------------------------------------------------------------------------------
+class _CSC:
+    __slots__ = ("offsets", "pair", "query", "keep")
+
+    def __init__(self, offsets, pair, query, keep):
+        self.offsets, self.pair, self.query, self.keep = offsets, pair, query, keep
+
+
+_CSC_CACHE = OrderedDict()
+_CSC_CACHE_SIZE = 8
+
+
+def csc_of(index0_offsets, index1, n_keys):
+    """Returns the cached CSC of (index0_offsets, index1); builds it on the current stream if absent.
+
+    The cache key is the identity (address + version) of the two index tensors; entries hold strong
+    references to them, so an address cannot be recycled for different contents while cached.
+    """
+    key = (index0_offsets.data_ptr(), index0_offsets._version, index1.data_ptr(), index1._version,
+           int(index1.shape[0]), int(n_keys), index1.device.index)
+    hit = _CSC_CACHE.get(key)
+    if hit is not None:
+        _CSC_CACHE.move_to_end(key)
+        return hit
+    M = int(index1.shape[0])
+    N = int(index0_offsets.shape[0]) - 1
+    if N != n_keys:
+        return None  # the launchers carry a single N (as the reference's do): fall back to their atomic path
+    dev = index1.device
+    l = _lib.lib()
+    offsets = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    pair = torch.empty(M, dtype=torch.int32, device=dev)
+    query = torch.empty(M, dtype=torch.int32, device=dev)
+    if M > 0:
+        nbytes = int(l.pointops2_csc_workspace_bytes(N, M))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("pointops2_csc_build", N, M, ptr(index0_offsets), ptr(index1), ptr(offsets), ptr(pair), ptr(query),
+                      ptr(ws), nbytes, device=dev)
+    else:
+        offsets.zero_()
+    csc = _CSC(offsets, pair, query, (index0_offsets, index1))
+    _CSC_CACHE[key] = csc
+    while len(_CSC_CACHE) > _CSC_CACHE_SIZE:
+        _CSC_CACHE.popitem(last=False)
+    return csc
+
+
+def clear_caches():
+    _CSC_CACHE.clear()
+
+
+class _with_csc:
+    def __init__(self, csc):
+        self.csc = csc
+
+    def __enter__(self):
+        if self.csc is not None:
+            _lib.lib().pointops2_set_csc(ptr(self.csc.offsets), ptr(self.csc.pair), ptr(self.csc.query))
+
+    def __exit__(self, *exc):
+        _lib.lib().pointops2_set_csc(None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# sampling / neighbours
+# ---------------------------------------------------------------------------------------------
+class FurthestSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, offset, new_offset):
+        """:14-29  xyz (n,3) f32, offset (b) i32, new_offset (b) i32 -> idx (m) i32"""
+        assert xyz.is_contiguous()
+        n, b = xyz.shape[0], offset.shape[0]
+        host = torch.stack([offset, new_offset]).tolist()  # one D2H copy (the reference loops .item(), :22-25)
+        offs, new_offs = host
+        n_max = offs[0]
+        for i in range(1, b):
+            n_max = max(offs[i] - offs[i - 1], n_max)
+        idx = _zeros(new_offs[b - 1], xyz, torch.int32)
+        tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
+        pointops_cuda.furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx)
+        del tmp
+        return idx
+
+
+furthestsampling = FurthestSampling.apply
+
+
+class KNNQuery(Function):
+    @staticmethod
+    def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
+        """:34-47  -> idx (m, nsample) i32, dist (m, nsample) f32 (Euclidean, sqrt applied here)"""
+        if new_xyz is None:
+            new_xyz = xyz
+        assert xyz.is_contiguous() and new_xyz.is_contiguous()
+        m = new_xyz.shape[0]
+        idx = _zeros((m, nsample), xyz, torch.int32)
+        dist2 = _zeros((m, nsample), xyz)
+        pointops_cuda.knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
+        return idx, torch.sqrt(dist2)
+
+
+knnquery = KNNQuery.apply
+
+
+class Grouping(Function):
+    @staticmethod
+    def forward(ctx, input, idx):
+        """:52-65  input (n,c), idx (m,nsample) -> (m,nsample,c)"""
+        assert input.is_contiguous() and idx.is_contiguous()
+        m, nsample, n, c = idx.shape[0], idx.shape[1], input.shape[0], input.shape[1]
+        output = torch.empty((m, nsample, c), dtype=torch.float32, device=input.device)
+        pointops_cuda.grouping_forward_cuda(m, nsample, c, input, idx, output)
+        ctx.n = n
+        ctx.save_for_backward(idx)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        n = ctx.n
+        idx, = ctx.saved_tensors
+        m, nsample, c = grad_output.shape
+        grad_input = _zeros((n, c), grad_output)
+        pointops_cuda.grouping_backward_cuda(m, nsample, c, grad_output.contiguous(), idx, grad_input)
+        return grad_input, None
+
+
+grouping = Grouping.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# A1
+# ---------------------------------------------------------------------------------------------
+class AttentionStep1(Function):
+    @staticmethod
+    def forward(ctx, q, k, index0, index1):
+        """:82-102  pair-indexed form -> (M, h)"""
+        assert q.is_contiguous() and k.is_contiguous() and index0.is_contiguous() and index1.is_contiguous()
+        N_q, h, C_div_h = q.shape
+        N_k = k.shape[0]
+        M = index0.shape[0]
+        C = int(C_div_h * h)
+        output = _zeros((M, h), q)
+        pointops_cuda.attention_step1_forward_cuda(N_k, M, h, C, q, k, index0, index1, output)
+        ctx.N_q, ctx.N_k, ctx.C = N_q, N_k, C
+        ctx.save_for_backward(q, k, index0, index1)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        N_q, N_k, C = ctx.N_q, ctx.N_k, ctx.C
+        q, k, index0, index1 = ctx.saved_tensors
+        M, h = grad_output.shape
+        grad_output = grad_output.contiguous()
+        grad_q = _zeros((N_q, h, C // h), q)
+        grad_k = _zeros((N_k, h, C // h), q)
+        pointops_cuda.attention_step1_backward_cuda(N_q, M, h, C, grad_output, index0, index1, q, k, grad_q, grad_k)
+        return grad_q, grad_k, None, None
+
+
+attention_step1 = AttentionStep1.apply
+
+
+class AttentionStep1_v2(Function):
+    @staticmethod
+    def forward(ctx, q, k, index1, index0_offsets, n_max):
+        """:142-164  q,k (N,h,d) f32; index1 (M) i32; index0_offsets (N+1) i32 -> (M,h)"""
+        assert q.is_contiguous() and k.is_contiguous() and index0_offsets.is_contiguous() and index1.is_contiguous()
+        N_q, h, C_div_h = q.shape
+        N_k = k.shape[0]
+        M = index1.shape[0]
+        C = int(C_div_h * h)
+        output = torch.empty((M, h), dtype=torch.float32, device=q.device)
+        pointops_cuda.attention_step1_forward_cuda_v2(N_k, M, h, C, _nmax(n_max), q, k, index0_offsets, index1, output)
+        ctx.N_q, ctx.N_k, ctx.C, ctx.n_max = N_q, N_k, C, n_max
+        ctx.save_for_backward(q, k, index0_offsets, index1)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        """:166-201 -> grad_q, grad_k, None, None, None"""
+        N_q, N_k, C = ctx.N_q, ctx.N_k, ctx.C
+        q, k, index0_offsets, index1 = ctx.saved_tensors
+        M, h = grad_output.shape
+        grad_output = grad_output.contiguous()
+        grad_q = torch.empty((N_q, h, C // h), dtype=torch.float32, device=q.device)
+        grad_k = _zeros((N_k, h, C // h), q)
+        with _with_csc(csc_of(index0_offsets, index1, N_k)):
+            pointops_cuda.attention_step1_backward_cuda_v2(N_q, M, h, C, _nmax(ctx.n_max), grad_output, index0_offsets, index1, q, k, grad_q, grad_k)
+        return grad_q, grad_k, None, None, None
+
+
+attention_step1_v2 = AttentionStep1_v2.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# plain AV (no rel-pos value)
+# ---------------------------------------------------------------------------------------------
+class AttentionStep2(Function):
+    @staticmethod
+    def forward(ctx, attn, v, index0, index1):
+        """:207-228  -> (N_q, h, d) with N_q = index0.max()+1"""
+        assert attn.is_contiguous() and v.is_contiguous() and index0.is_contiguous() and index1.is_contiguous()
+        M, h = attn.shape
+        N_q = index0.max().item() + 1
+        N_v, h, C_div_h = v.shape
+        C = int(C_div_h * h)
+        output = _zeros((N_q, h, C // h), v)
+        pointops_cuda.attention_step2_forward_cuda(N_q, M, h, C, attn, v, index0, index1, output)
+        ctx.M = M
+        ctx.save_for_backward(attn, v, index0, index1)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        M = ctx.M
+        attn, v, index0, index1 = ctx.saved_tensors
+        N_v = v.shape[0]
+        N_q, h, C_div_h = grad_output.shape
+        C = h * C_div_h
+        grad_output = grad_output.contiguous()
+        grad_attn = _zeros((M, h), v)
+        grad_v = _zeros((N_v, h, C // h), v)
+        pointops_cuda.attention_step2_backward_cuda(N_q, M, h, C, grad_output, index0, index1, attn, v, grad_attn, grad_v)
+        return grad_attn, grad_v, None, None
+
+
+attention_step2 = AttentionStep2.apply
+
+
+class AttentionStep2_v2(Function):
+    """:268-316 — identical math; the reference routes it to the v1 kernel (:284)."""
+
+    @staticmethod
+    def forward(ctx, attn, v, index0, index1):
+        return AttentionStep2.forward(ctx, attn, v, index0, index1)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return AttentionStep2.backward(ctx, grad_output)
+
+
+attention_step2_v2 = AttentionStep2_v2.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# A2
+# ---------------------------------------------------------------------------------------------
+class DotProdWithIdx(Function):
+    @staticmethod
+    def forward(ctx, q, index, table, rel_idx):
+        """:320-335  single-table pair-indexed form -> (M, h)"""
+        assert q.is_contiguous() and index.is_contiguous() and table.is_contiguous() and rel_idx.is_contiguous()
+        N, h, hdim = q.shape
+        M = index.shape[0]
+        output = _zeros((M, h), q)
+        pointops_cuda.dot_prod_with_idx_forward_cuda(N, M, h, hdim, q, index, table, rel_idx, output)
+        ctx.save_for_backward(q, index, table, rel_idx)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        q, index, table, rel_idx = ctx.saved_tensors
+        M, h = grad_output.shape
+        N, _, hdim = q.shape
+        L = table.shape[0]
+        grad_output = grad_output.contiguous()
+        grad_q = _zeros((N, h, hdim), q)
+        grad_table = _zeros((L, h, hdim, 3), q)
+        pointops_cuda.dot_prod_with_idx_backward_cuda(N, M, h, hdim, grad_output, q, index, table, rel_idx, grad_q, grad_table)
+        return grad_q, None, grad_table, None
+
+
+dot_prod_with_idx = DotProdWithIdx.apply
+
+
+class DotProdWithIdx_v2(Function):
+    @staticmethod
+    def forward(ctx, q, index_q, k, index_k, table_q, table_k, rel_idx):
+        """:372-406  bucketed form.  The host-side sort by merged rel index (:387-393) only drives the
+        reference's work distribution; the result does not depend on it, so it is not computed here."""
+        assert q.is_contiguous() and index_q.is_contiguous() and k.is_contiguous() and index_k.is_contiguous() \
+            and table_q.is_contiguous() and table_k.is_contiguous() and rel_idx.is_contiguous()
+        N, h, hdim = q.shape
+        M = index_q.shape[0]
+        L = table_q.shape[0]
+        assert table_k.shape[0] == L and index_k.shape[0] == M
+        output = _zeros((M, h), q)
+        pointops_cuda.dot_prod_with_idx_forward_cuda_v2(N, M, h, hdim, 0, 0, q, index_q, k, index_k, table_q, table_k, rel_idx, None, None, output)
+        ctx.save_for_backward(q, index_q, k, index_k, table_q, table_k, rel_idx)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        q, index_q, k, index_k, table_q, table_k, rel_idx = ctx.saved_tensors
+        M, h = grad_output.shape
+        N, _, hdim = q.shape
+        L = table_q.shape[0]
+        grad_output = grad_output.contiguous()
+        grad_q, grad_k = _zeros((N, h, hdim), q), _zeros((N, h, hdim), q)
+        grad_table_q, grad_table_k = _zeros((L, h, hdim, 3), q), _zeros((L, h, hdim, 3), q)
+        pointops_cuda.dot_prod_with_idx_backward_cuda_v2(N, M, h, hdim, 0, 0, grad_output, q, index_q, k, index_k, table_q, table_k, rel_idx,
+                                                         None, None, grad_q, grad_k, grad_table_q, grad_table_k)
+        return grad_q, None, grad_k, None, grad_table_q, grad_table_k, None
+
+
+dot_prod_with_idx_v2 = DotProdWithIdx_v2.apply
+
+
+class DotProdWithIdx_v3(Function):
+    @staticmethod
+    def forward(ctx, q, index_q_offsets, n_max, k, index_k, table_q, table_k, rel_idx):
+        """:446-482  -> (M, h)"""
+        assert q.is_contiguous() and index_q_offsets.is_contiguous() and k.is_contiguous() and index_k.is_contiguous() \
+            and table_q.is_contiguous() and table_k.is_contiguous() and rel_idx.is_contiguous()
+        N, h, hdim = q.shape
+        M = index_k.shape[0]
+        L = table_q.shape[0]
+        assert table_k.shape[0] == L
+        output = torch.empty((M, h), dtype=torch.float32, device=q.device)
+        pointops_cuda.dot_prod_with_idx_forward_cuda_v3(N, M, h, hdim, _nmax(n_max), q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output)
+        ctx.n_max = n_max
+        ctx.save_for_backward(q, index_q_offsets, k, index_k, table_q, table_k, rel_idx)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        """:484-517 -> grad_q, None, None, grad_k, None, grad_table_q, grad_table_k, None"""
+        q, index_q_offsets, k, index_k, table_q, table_k, rel_idx = ctx.saved_tensors
+        M, h = grad_output.shape
+        N, _, hdim = q.shape
+        L = table_q.shape[0]
+        grad_output = grad_output.contiguous()
+        grad_q = torch.empty((N, h, hdim), dtype=torch.float32, device=q.device)
+        grad_k = _zeros((k.shape[0], h, hdim), q)
+        grad_table_q, grad_table_k = _zeros((L, h, hdim, 3), q), _zeros((L, h, hdim, 3), q)
+        with _with_csc(csc_of(index_q_offsets, index_k, k.shape[0])):
+            pointops_cuda.dot_prod_with_idx_backward_cuda_v3(N, M, h, hdim, _nmax(ctx.n_max), grad_output, q, index_q_offsets, k, index_k,
+                                                             table_q, table_k, rel_idx, grad_q, grad_k, grad_table_q, grad_table_k)
+        return grad_q, None, None, grad_k, None, grad_table_q, grad_table_k, None
+
+
+dot_prod_with_idx_v3 = DotProdWithIdx_v3.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# A4
+# ---------------------------------------------------------------------------------------------
+class AttentionStep2WithRelPosValue(Function):
+    @staticmethod
+    def forward(ctx, attn, v, index0, index1, table, rel_idx):
+        """:521-540  pair-indexed form -> (N_q, h, hdim)"""
+        assert attn.is_contiguous() and v.is_contiguous() and index0.is_contiguous() and index1.is_contiguous() \
+            and table.is_contiguous() and rel_idx.is_contiguous()
+        M, h = attn.shape
+        N_v, h, hdim = v.shape
+        N_q = index0.max().item() + 1
+        output = _zeros((N_q, h, hdim), v)
+        pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda(N_q, M, h, hdim, attn, v, index0, index1, table, rel_idx, output)
+        ctx.save_for_backward(attn, v, index0, index1, table, rel_idx)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        attn, v, index0, index1, table, rel_idx = ctx.saved_tensors
+        N_q, h, hdim = grad_output.shape
+        N_v, M, L = v.shape[0], attn.shape[0], table.shape[0]
+        grad_output = grad_output.contiguous()
+        grad_attn, grad_v, grad_table = _zeros((M, h), v), _zeros((N_v, h, hdim), v), _zeros((L, h, hdim, 3), v)
+        pointops_cuda.attention_step2_with_rel_pos_value_backward_cuda(N_q, M, h, hdim, grad_output, index0, index1, attn, v, table, rel_idx,
+                                                                       grad_attn, grad_v, grad_table)
+        return grad_attn, grad_v, None, None, grad_table, None
+
+
+attention_step2_with_rel_pos_value = AttentionStep2WithRelPosValue.apply
+
+
+class AttentionStep2WithRelPosValue_v2(Function):
+    @staticmethod
+    def forward(ctx, attn, v, index0_offsets, n_max, index1, table, rel_idx):
+        """:584-604  attn (M,h), v (N,h,hdim) -> (N,h,hdim)"""
+        assert attn.is_contiguous() and v.is_contiguous() and index0_offsets.is_contiguous() and index1.is_contiguous() \
+            and table.is_contiguous() and rel_idx.is_contiguous()
+        M, h = attn.shape
+        N, h, hdim = v.shape
+        output = _zeros((N, h, hdim), v)  # queries beyond the CSR (none in the model) stay zero
+        pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, _nmax(n_max), attn, v, index0_offsets, index1, table, rel_idx, output)
+        ctx.n_max = n_max
+        ctx.save_for_backward(attn, v, index0_offsets, index1, table, rel_idx)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        """:606-644 -> grad_attn, grad_v, None, None, None, grad_table, None (grad_output must be contiguous, :621)"""
+        attn, v, index0_offsets, index1, table, rel_idx = ctx.saved_tensors
+        N, h, hdim = v.shape
+        M, L = attn.shape[0], table.shape[0]
+        assert grad_output.is_contiguous()
+        grad_attn = torch.empty((M, h), dtype=torch.float32, device=v.device)
+        grad_v, grad_table = _zeros((N, h, hdim), v), _zeros((L, h, hdim, 3), v)
+        with _with_csc(csc_of(index0_offsets, index1, N)):
+            pointops_cuda.attention_step2_with_rel_pos_value_backward_cuda_v2(N, M, h, hdim, _nmax(ctx.n_max), grad_output, index0_offsets, index1,
+                                                                              attn, v, table, rel_idx, grad_attn, grad_v, grad_table)
+        return grad_attn, grad_v, None, None, None, grad_table, None
+
+
+attention_step2_with_rel_pos_value_v2 = AttentionStep2WithRelPosValue_v2.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# A3 (not part of the reference module: the model takes it from torch_scatter)
+# ---------------------------------------------------------------------------------------------
+class SegmentSoftmax(Function):
+    """softmax over each CSR segment of src (M, h), per head."""
+
+    @staticmethod
+    def forward(ctx, src, offsets):
+        src = src.contiguous()
+        M, h = src.shape
+        N = offsets.shape[0] - 1
+        out = torch.empty_like(src)
+        with torch.cuda.device(src.device):
+            _lib.call("segment_softmax_forward_launcher", N, M, h, ptr(src), ptr(offsets), ptr(out), device=src.device)
+        ctx.save_for_backward(out, offsets)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        out, offsets = ctx.saved_tensors
+        M, h = out.shape
+        N = offsets.shape[0] - 1
+        grad_out = grad_out.contiguous()
+        grad_src = torch.empty_like(out)
+        with torch.cuda.device(out.device):
+            _lib.call("segment_softmax_backward_launcher", N, M, h, ptr(out), ptr(grad_out), ptr(offsets), ptr(grad_src), device=out.device)
+        return grad_src, None
+
+
+segment_softmax = SegmentSoftmax.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers around kNN (:648-693, :756-833)
+# ---------------------------------------------------------------------------------------------
+def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=True, return_indx=False):
+    """:648-675  -> (m, nsample, 3+c) or (m, nsample, c)"""
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
+    if new_xyz is None:
+        new_xyz = xyz
+    if idx is None:
+        idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)
+    n, m, c = xyz.shape[0], new_xyz.shape[0], feat.shape[1]
+    flat = idx.view(-1).long()
+    grouped_feat = feat[flat, :].view(m, nsample, c)
+    if use_xyz:
+        grouped_xyz = xyz[flat, :].view(m, nsample, 3)
+        grouped_xyz -= new_xyz.unsqueeze(1)
+        out = torch.cat((grouped_xyz, grouped_feat), -1)
+    else:
+        out = grouped_feat
+    return (out, idx) if return_indx else out
+
+
+def Divide2Patch(nsample, xyz, offset, return_offset=False, anchor_scale=None):
+    """:678-693"""
+    downsample_scale = anchor_scale or nsample
+    offs = offset.tolist()
+    new_offset, count = [offs[0] // downsample_scale], offs[0] // downsample_scale
+    for i in range(1, len(offs)):
+        count += (offs[i] - offs[i - 1]) // downsample_scale
+        new_offset.append(count)
+    new_offset = torch.tensor(new_offset, dtype=torch.int32, device=xyz.device)
+    idx = furthestsampling(xyz, offset, new_offset)
+    new_xyz = xyz[idx.long()]
+    p_idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)
+    return (p_idx, new_offset) if return_offset else p_idx
+
+
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
+    """:756-770  inverse-distance weighted k-NN interpolation (differentiable w.r.t. feat via torch indexing)"""
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
+    idx, dist = knnquery(k, xyz, new_xyz, offset, new_offset)
+    dist_recip = 1.0 / (dist + 1e-8)
+    norm = torch.sum(dist_recip, dim=1, keepdim=True)
+    weight = dist_recip / norm
+    new_feat = _zeros((new_xyz.shape[0], feat.shape[1]), feat)
+    for i in range(k):
+        new_feat += feat[idx[:, i].long(), :] * weight[:, i].unsqueeze(-1)
+    return new_feat
+
+
+def interpolation_v2(xyz, new_xyz, feat, offset, new_offset, k=3):
+    """:773-797"""
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
+    idx, _ = knnquery(k, xyz, new_xyz, offset, new_offset)
+    dist = torch.sqrt(((new_xyz.unsqueeze(1) - xyz[idx.long()]) ** 2).sum(-1) + 1e-8)
+    dist_recip = 1.0 / (dist + 1e-8)
+    norm = torch.sum(dist_recip, dim=1, keepdim=True)
+    weight = dist_recip / norm
+    new_feat = _zeros((new_xyz.shape[0], feat.shape[1]), feat)
+    for i in range(k):
+        new_feat += feat[idx[:, i].long(), :] * weight[:, i].unsqueeze(-1)
+    return new_feat
+
+
+class Interpolation(Function):
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, input, offset, new_offset, k=3):
+        """:800-818"""
+        assert xyz.is_contiguous() and new_xyz.is_contiguous() and input.is_contiguous()
+        idx, dist = knnquery(k, xyz, new_xyz, offset, new_offset)
+        dist_recip = 1.0 / (dist + 1e-8)
+        norm = torch.sum(dist_recip, dim=1, keepdim=True)
+        weight = (dist_recip / norm).contiguous()
+        n, c, m = new_xyz.shape[0], input.shape[1], input.shape[0]
+        output = _zeros((n, c), input)
+        pointops_cuda.interpolation_forward_cuda(n, c, k, input, idx, weight, output)
+        ctx.m, ctx.k = m, k
+        ctx.save_for_backward(idx, weight)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        m, k = ctx.m, ctx.k
+        idx, weight = ctx.saved_tensors
+        n, c = grad_output.shape
+        grad_input = _zeros((m, c), grad_output)
+        pointops_cuda.interpolation_backward_cuda(n, c, k, grad_output.contiguous(), idx, weight, grad_input)
+        return None, None, grad_input, None, None, None
+
+
+interpolation2 = Interpolation.apply
+
+
+class Subtraction(Function):
+    @staticmethod
+    def forward(ctx, input1, input2, idx):
+        raise NotImplementedError("subtraction: Point-Transformer op outside the Stratified hot path (SURVEY.md §8)")
+
+
+class Aggregation(Function):
+    @staticmethod
+    def forward(ctx, input, position, weight, idx):
+        raise NotImplementedError("aggregation: Point-Transformer op outside the Stratified hot path (SURVEY.md §8)")
+
+
+subtraction = Subtraction.apply
+aggregation = Aggregation.apply

@@ -1,0 +1,164 @@
+"""CPU: host-side logic of the product (index build orchestration, third-party shims, the C-ABI
+surface).  No HIP compute is executed here (there is no GPU in the build container)."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import stratified_transformer_amd as sta
+from stratified_transformer_amd import _lib, compat, index_build
+from oracle import index_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ---- index build vs the golden vectors of the reference -------------------------------------
+def test_partitions_match_reference_grid_sample(golden):
+    xyz = _t(golden["xyz"])
+    parts = index_build.stage_partitions(xyz, _t(golden["offset"]), float(golden["window_size"]))
+    for name, part in parts.items():
+        assert np.array_equal(part.cluster.numpy(), golden[f"grid_{name}_cluster"]), name
+        p2v, cnt = index_build.p2v_map(part)
+        assert np.array_equal(p2v.numpy(), golden[f"grid_{name}_p2v"]), name
+        assert np.array_equal(cnt.numpy(), golden[f"grid_{name}_counts"]), name
+
+
+def test_block_index_matches_reference_pairs(golden):
+    xyz = _t(golden["xyz"])
+    w, quant = float(golden["window_size"]), float(golden["quant_size"])
+    parts = index_build.stage_partitions(xyz, _t(golden["offset"]), w)
+    for i in (0, 1):
+        s, l = ("small", "large") if i == 0 else ("small_shift", "large_shift")
+        blk = index_build.build_block_index(xyz, parts[s], parts[l], _t(golden["downsample_idx"]), w, quant, shifted=(i == 1))
+        assert np.array_equal(blk.index_0.numpy(), golden[f"blk{i}_index_0"])
+        assert np.array_equal(blk.index_1.numpy(), golden[f"blk{i}_index_1"])
+        assert np.array_equal(blk.offsets.numpy(), golden[f"blk{i}_offsets"])
+        assert int(blk.n_max) == int(golden[f"blk{i}_n_max"])
+        # GPU arithmetic for /100000: equals the oracle's "cuda" mode exactly, the CPU golden up to rare floor flips
+        want = index_ref.rel_pos_index(xyz, _t(golden[f"blk{i}_index_0"]).long(), _t(golden[f"blk{i}_index_1"]).long(), w, quant, "cuda")
+        assert np.array_equal(blk.rel_idx.numpy(), want.numpy())
+        assert (blk.rel_idx.numpy() != golden[f"blk{i}_rel_idx_cpu"]).mean() < 1e-3
+
+
+def test_block_index_against_oracle_random_scenes():
+    for seed, n, w in ((3, 700, 0.25), (4, 1200, 0.4)):
+        g = torch.Generator().manual_seed(seed)
+        xyz = torch.rand(n, 3, generator=g) * torch.tensor([2.0, 1.5, 0.3])
+        xyz = (xyz - xyz.min(0)[0]).contiguous()
+        offset = torch.tensor([n // 3, n], dtype=torch.int32)
+        ds = torch.randperm(n, generator=g)[: n // 6].sort()[0].int()
+        parts = index_build.stage_partitions(xyz, offset, w)
+        for i in (0, 1):
+            s, l = ("small", "large") if i == 0 else ("small_shift", "large_shift")
+            blk = index_build.build_block_index(xyz, parts[s], parts[l], ds, w, w / 16, shifted=(i == 1))
+            ref = index_ref.build_stage_indices(xyz, offset.numpy(), w, w / 16, ds, i, div_mode="cuda")
+            assert np.array_equal(blk.index_1.numpy(), ref["index_1"].numpy())
+            assert np.array_equal(blk.offsets.numpy(), ref["offsets"].numpy())
+            assert np.array_equal(blk.rel_idx.numpy(), ref["rel_idx"].numpy())
+
+
+def test_offset_rules_match_oracle():
+    for offs in ([600, 1000], [10, 20, 30], [100000]):
+        assert index_build.stratified_new_offset(offs, 8) == index_ref.stratified_new_offset(offs, 8).tolist()
+        assert index_build.transition_down_offset(offs, 0.25) == index_ref.transition_down_offset(offs, 0.25).tolist()
+    b = index_build.batch_ids(torch.tensor([3, 5], dtype=torch.int32), 5)
+    assert b.tolist() == [0, 0, 0, 1, 1]
+
+
+# ---- third-party shims ------------------------------------------------------------------------
+def test_voxel_grid_shim_matches_oracle(golden):
+    xyz = _t(golden["xyz"])
+    batch = index_ref.batch_from_offset(golden["offset"])
+    ws = torch.tensor([0.16] * 3)
+    for start in (None, xyz.min(0)[0]):
+        a = compat.voxel_grid(xyz, batch, ws, start=start)
+        b = index_ref.voxel_grid(xyz, batch, ws, start=start)
+        assert torch.equal(a, b)
+
+
+def test_scatter_softmax_generic_matches_golden(golden):
+    y = compat.scatter_softmax(_t(golden["op_a1_out"] + golden["op_a2_out"]), _t(golden["blk0_index_0"]).long(), dim=0)
+    np.testing.assert_allclose(y.numpy(), golden["op_a3_out"], rtol=2e-5, atol=2e-6)
+    # unsorted index and dim=-1 form
+    src = torch.randn(5, 7)
+    idx = torch.tensor([2, 0, 2, 1, 0, 1, 2])
+    out = compat.scatter_softmax(src, idx, dim=-1)
+    for g in range(3):
+        np.testing.assert_allclose(out[:, idx == g].sum(-1).numpy(), np.ones(5), rtol=1e-5)
+
+
+def test_install_registers_dropin_modules():
+    import sys
+    sta.install()
+    import pointops2_cuda
+    assert pointops2_cuda is sta.pointops2_cuda
+    from torch_scatter import scatter_softmax  # noqa: F401
+    from torch_geometric.nn import voxel_grid  # noqa: F401
+    from timm.models.layers import DropPath, trunc_normal_  # noqa: F401
+    from torch_points3d.modules.KPConv.kernels import KPConvLayer  # noqa: F401
+    from torch_points3d.core.common_modules import FastBatchNorm1d  # noqa: F401
+    from lib.pointops2.functions import pointops
+    for name in ("furthestsampling", "knnquery", "queryandgroup", "interpolation", "attention_step1", "attention_step1_v2",
+                 "attention_step2", "dot_prod_with_idx", "dot_prod_with_idx_v3", "attention_step2_with_rel_pos_value_v2",
+                 "grouping", "interpolation2", "dot_prod_with_idx_v2", "attention_step2_v2", "attention_step2_with_rel_pos_value"):
+        assert callable(getattr(pointops, name)), name
+    assert "pointops2_cuda" in sys.modules
+
+
+def test_operator_signatures_match_reference_api():
+    """Positional parameter names of every forward(), as in lib/pointops2/functions/pointops.py."""
+    from stratified_transformer_amd import pointops as P
+    want = {
+        "FurthestSampling": ["ctx", "xyz", "offset", "new_offset"],                                   # :16
+        "KNNQuery": ["ctx", "nsample", "xyz", "new_xyz", "offset", "new_offset"],                     # :36
+        "Grouping": ["ctx", "input", "idx"],                                                          # :54
+        "AttentionStep1": ["ctx", "q", "k", "index0", "index1"],                                      # :84
+        "AttentionStep1_v2": ["ctx", "q", "k", "index1", "index0_offsets", "n_max"],                  # :144
+        "AttentionStep2": ["ctx", "attn", "v", "index0", "index1"],                                   # :209
+        "DotProdWithIdx": ["ctx", "q", "index", "table", "rel_idx"],                                  # :322
+        "DotProdWithIdx_v2": ["ctx", "q", "index_q", "k", "index_k", "table_q", "table_k", "rel_idx"],  # :374
+        "DotProdWithIdx_v3": ["ctx", "q", "index_q_offsets", "n_max", "k", "index_k", "table_q", "table_k", "rel_idx"],  # :448
+        "AttentionStep2WithRelPosValue": ["ctx", "attn", "v", "index0", "index1", "table", "rel_idx"],  # :523
+        "AttentionStep2WithRelPosValue_v2": ["ctx", "attn", "v", "index0_offsets", "n_max", "index1", "table", "rel_idx"],  # :586
+        "Interpolation": ["ctx", "xyz", "new_xyz", "input", "offset", "new_offset", "k"],             # :802
+    }
+    for cls, params in want.items():
+        assert list(inspect.signature(getattr(P, cls).forward).parameters) == params, cls
+    assert list(inspect.signature(P.queryandgroup).parameters) == ["nsample", "xyz", "new_xyz", "feat", "idx", "offset", "new_offset", "use_xyz", "return_indx"]
+    assert list(inspect.signature(P.interpolation).parameters) == ["xyz", "new_xyz", "feat", "offset", "new_offset", "k"]
+
+
+# ---- C ABI ------------------------------------------------------------------------------------
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "pointops2_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b([a-z_0-9]+)\s*\(", " ".join(l for l in text.splitlines() if not l.strip().startswith("#")))) - {"defined"})
+
+
+def test_library_exports_every_symbol_of_the_header():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    names = _header_functions()
+    assert len(names) >= 30
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(l, n), f"{n} declared in include/pointops2_hip.h but not exported"
+    assert set(_lib.exported_symbols()) == set(names), set(_lib.exported_symbols()) ^ set(names)
+    assert _lib.lib().pointops2_abi_version() >= 1
+
+
+def test_product_path_fails_loudly_without_gpu_tensors():
+    from stratified_transformer_amd import pointops as P
+    q = torch.zeros(4, 3, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.attention_step1_v2(q, q, torch.zeros(4, dtype=torch.int32), torch.arange(5, dtype=torch.int32), 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.furthestsampling(torch.zeros(8, 3), torch.tensor([8], dtype=torch.int32), torch.tensor([2], dtype=torch.int32))

@@ -76,32 +76,42 @@ void oracle_furthestsampling(int b, int n, const float *xyz, const int *offset,
         int end_m = new_offset[bid];
         int old = start_n;
         idx[start_m] = start_n;
+        /* One thread team for all iterations.  "CUDA thread" tid owns points start+tid, start+tid+B, ...
+           (:49); the loops below walk them chunk-major so memory is swept linearly, which visits every
+           thread's points in the same ascending order as the kernel does. */
+#pragma omp parallel
         for (int j = start_m + 1; j < end_m; j++) {
             float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
-#pragma omp parallel for schedule(static)
-            for (int tid = 0; tid < B; tid++) {
-                int besti = start_n;
-                float best = -1;
-                for (int k = start_n + tid; k < end_n; k += B) {
+#pragma omp for schedule(static)
+            for (int tid = 0; tid < B; tid++) { dists[tid] = -1; dists_i[tid] = start_n; }
+            int nt = omp_get_num_threads(), me = omp_get_thread_num();
+            int t0 = (int)((long long)B * me / nt), t1 = (int)((long long)B * (me + 1) / nt);
+            for (int base = start_n; base < end_n; base += B) {
+                int hi = t1 < end_n - base ? t1 : end_n - base;
+                for (int tid = t0; tid < hi; tid++) {
+                    int k = base + tid;
                     float d = sqdist(x1, y1, z1, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
                     float d2 = fminf(d, tmp[k]);
                     tmp[k] = d2;
-                    besti = d2 > best ? k : besti;
-                    best = d2 > best ? d2 : best;
-                }
-                dists[tid] = best;
-                dists_i[tid] = besti;
-            }
-            for (int s = B / 2; s >= 1; s >>= 1) {
-                for (int tid = 0; tid < s; tid++) {
-                    float v1 = dists[tid], v2 = dists[tid + s];
-                    int i1 = dists_i[tid], i2 = dists_i[tid + s];
-                    dists[tid] = v1 > v2 ? v1 : v2; /* max(v1, v2) */
-                    dists_i[tid] = v2 > v1 ? i2 : i1;
+                    float best = dists[tid];
+                    dists_i[tid] = d2 > best ? k : dists_i[tid];
+                    dists[tid] = d2 > best ? d2 : best;
                 }
             }
-            old = dists_i[0];
-            idx[j] = old;
+#pragma omp barrier
+#pragma omp single
+            {
+                for (int s = B / 2; s >= 1; s >>= 1) {
+                    for (int tid = 0; tid < s; tid++) {
+                        float v1 = dists[tid], v2 = dists[tid + s];
+                        int i1 = dists_i[tid], i2 = dists_i[tid + s];
+                        dists[tid] = v1 > v2 ? v1 : v2; /* max(v1, v2) */
+                        dists_i[tid] = v2 > v1 ? i2 : i1;
+                    }
+                }
+                old = dists_i[0];
+                idx[j] = old;
+            } /* implicit barrier: every thread sees the new `old` */
         }
     }
     free(dists);

@@ -1,0 +1,180 @@
+"""One pass of the StratifiedAttention hot path over a scene — the unit bench.py times
+ and the full-size tests exercise.
+
+For each stage s of a Stratified config (window w_s, quant q_s, C_s, h_s, depth_s):
+    index build   four window partitions (grid_sample x4), stratified FPS (n//scale+1 per batch
+                  element), pair list + rel-pos index for the even and the odd block pattern
+    attention     depth_s x [A1, A2, add, A3, A4] forward and backward through the operator API
+    transition    TransitionDown's FPS (ratio) + kNN(k) producing stage s+1's points
+    upsample      kNN(k=3) of Upsample between stage s+1 and s
+Linear layers (qkv/proj/MLP) are not part of the unit.
+"""
+from dataclasses import dataclass, field
+
+import torch
+
+from . import index_build
+from . import pointops as P
+
+
+@dataclass
+class StageConfig:
+    window_size: float
+    quant_size: float
+    channels: int
+    num_heads: int
+    depth: int
+
+
+@dataclass
+class SceneConfig:
+    name: str
+    stages: list
+    downsample_scale: int = 8
+    ratio: float = 0.25
+    k: int = 16
+    up_k: int = 3
+    stem_transformer: bool = True
+
+
+def s3dis_config():
+    """config/s3dis/s3dis_stratified_transformer.yaml:14-35 with the derivations of train.py:110-113"""
+    grid, win, quant = 0.04, 4, 0.01
+    ch, heads, depths = [48, 96, 192, 384], [3, 6, 12, 24], [2, 2, 6, 2]
+    return SceneConfig("s3dis_stratified_transformer",
+                       [StageConfig(grid * win * 2 ** i, quant * 2 ** i, ch[i], heads[i], depths[i]) for i in range(4)],
+                       downsample_scale=8, ratio=0.25, k=16, up_k=3, stem_transformer=True)
+
+
+def scannet_config():
+    """config/scannetv2/scannetv2_stratified_transformer.yaml:13-34; stem_transformer False => attention
+    starts at stage 1 after a TransitionDown (model/stratified_transformer.py:411-417)"""
+    grid, win, quant = 0.02, 5, 0.005
+    ch, heads, depths = [48, 96, 192, 384, 384], [3, 6, 12, 24, 24], [3, 3, 9, 3, 3]
+    return SceneConfig("scannetv2_stratified_transformer",
+                       [StageConfig(grid * win * 2 ** i, quant * 2 ** i, ch[i], heads[i], depths[i]) for i in range(5)],
+                       downsample_scale=4, ratio=0.25, k=16, up_k=3, stem_transformer=False)
+
+
+@dataclass
+class StageState:
+    """Resident tensors of one stage (synthetic q/k/v/tables/grad_out stand in for the Linear layers)."""
+    xyz: torch.Tensor
+    offset: torch.Tensor
+    q: torch.Tensor = None
+    k: torch.Tensor = None
+    v: torch.Tensor = None
+    tables: list = field(default_factory=list)
+    grad_out: torch.Tensor = None
+
+
+class Timer:
+    """Per-component device timing with events on torch's current stream (the stream every HIP launch
+    of this package uses).  Disabled timers cost nothing."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+        self.spans = []
+
+    def run(self, name, fn, *a, **k):
+        if not self.enabled:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **k)
+        e1.record()
+        self.spans.append((name, e0, e1))
+        return out
+
+    def totals(self):
+        """-> {name: (total_ms, calls)}; call after torch.cuda.synchronize()"""
+        out = {}
+        for name, e0, e1 in self.spans:
+            t, c = out.get(name, (0.0, 0))
+            out[name] = (t + e0.elapsed_time(e1), c + 1)
+        return out
+
+
+def make_stage_state(xyz, offset, st, seed):
+    g = torch.Generator(device=xyz.device).manual_seed(seed)
+    n, h, d = xyz.shape[0], st.num_heads, st.channels // st.num_heads
+    L = 2 * int((2 * st.window_size + 1e-4) // st.quant_size)  # model/stratified_transformer.py:142,145
+
+    def rn(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g, device=xyz.device) * scale).requires_grad_(True)
+
+    return StageState(xyz, offset, rn(n, h, d), rn(n, h, d), rn(n, h, d),
+                      [rn(L, h, d, 3, scale=0.02) for _ in range(3)],
+                      torch.randn(n, h, d, generator=g, device=xyz.device))
+
+
+def attention_block(state, blk, timer):
+    """WindowAttention.forward's op sequence (model/stratified_transformer.py:183-208) + its backward."""
+    q, k, v = state.q, state.k, state.v
+    tq, tk, tv = state.tables
+    for t in (q, k, v, tq, tk, tv):
+        t.grad = None
+    a1 = timer.run("attn_fwd/A1", P.attention_step1_v2, q, k, blk.index_1, blk.offsets, blk.n_max)
+    a2 = timer.run("attn_fwd/A2", P.dot_prod_with_idx_v3, q, blk.offsets, blk.n_max, k, blk.index_1, tq, tk, blk.rel_idx)
+    s = timer.run("attn_fwd/add", torch.add, a1, a2)
+    sm = timer.run("attn_fwd/A3", P.segment_softmax, s, blk.offsets)
+    out = timer.run("attn_fwd/A4", P.attention_step2_with_rel_pos_value_v2, sm, v, blk.offsets, blk.n_max, blk.index_1, tv, blk.rel_idx)
+    timer.run("attn_bwd", out.backward, state.grad_out)
+    return out
+
+
+def stage_index_build(xyz, offset, offset_host, st, cfg, timer):
+    parts = timer.run("index/partition", index_build.stage_partitions, xyz, offset, st.window_size)
+    new_offset = torch.tensor(index_build.stratified_new_offset(offset_host, cfg.downsample_scale), dtype=torch.int32, device=xyz.device)
+    ds = timer.run("fps/stratified", P.furthestsampling, xyz, offset, new_offset)
+    even = timer.run("index/pairs", index_build.build_block_index, xyz, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)
+    odd = timer.run("index/pairs", index_build.build_block_index, xyz, parts["small_shift"], parts["large_shift"], ds, st.window_size, st.quant_size, True)
+    return even, odd, ds
+
+
+def transition_down(xyz, offset, offset_host, cfg, timer):
+    """TransitionDown.forward's sampling + grouping indices (:98-106) -> next stage's xyz/offset, knn idx"""
+    n_off_host = index_build.transition_down_offset(offset_host, cfg.ratio)
+    n_offset = torch.tensor(n_off_host, dtype=torch.int32, device=xyz.device)
+    idx = timer.run("fps/transition", P.furthestsampling, xyz, offset, n_offset)
+    n_xyz = xyz[idx.long(), :].contiguous()
+    knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, xyz, n_xyz, offset, n_offset)
+    return n_xyz, n_offset, n_off_host, knn_idx
+
+
+def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0):
+    """Runs the whole unit once.  `states` (list of StageState) carries the resident synthetic tensors;
+    pass None on the first call to have them created (not timed by bench.py).  Returns (states, results)."""
+    timer = timer or Timer(False)
+    offset_host = [int(o) for o in offset.tolist()]
+    make = states is None
+    states = [] if make else states
+    results = []
+    cur_xyz, cur_off, cur_off_host = xyz, offset, offset_host
+    first = 0 if cfg.stem_transformer else 1
+    if not cfg.stem_transformer:  # Stratified.forward :458-462: a TransitionDown precedes the first attention stage
+        cur_xyz, cur_off, cur_off_host, _ = transition_down(cur_xyz, cur_off, cur_off_host, cfg, timer)
+    stack = []
+    for si in range(first, len(cfg.stages)):
+        st = cfg.stages[si]
+        if make:
+            states.append(make_stage_state(cur_xyz, cur_off, st, seed + si))
+        state = states[si - first]
+        state.xyz, state.offset = cur_xyz, cur_off
+        even, odd, ds = stage_index_build(cur_xyz, cur_off, cur_off_host, st, cfg, timer)
+        out = None
+        for b in range(st.depth):
+            out = attention_block(state, even if b % 2 == 0 else odd, timer)
+        results.append(dict(stage=si, n=cur_xyz.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),
+                            even=even, odd=odd, downsample_idx=ds, out=out))
+        stack.append((cur_xyz, cur_off))
+        if si < len(cfg.stages) - 1:
+            cur_xyz, cur_off, cur_off_host, knn_idx = transition_down(cur_xyz, cur_off, cur_off_host, cfg, timer)
+            results[-1]["transition_knn"] = knn_idx
+    # Upsample chain (:479-480): interpolate from the coarse stage back to each finer one (kNN k=up_k)
+    coarse_xyz, coarse_off = stack.pop()
+    while stack:
+        fine_xyz, fine_off = stack.pop()
+        timer.run("knn/k3", P.knnquery, cfg.up_k, coarse_xyz, fine_xyz, coarse_off, fine_off)
+        coarse_xyz, coarse_off = fine_xyz, fine_off
+    return states, results

@@ -34,6 +34,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 def algorithmic_bytes(op, info):
     """SURVEY.md §8(d) per-op compulsory bytes (fp32/int32), for one launch of `op` at stage `info`."""
+    if op.startswith("fps/"):
+        # per iteration: read xyz (12 B) + min-dist (4 B) and write min-dist (4 B) for every point
+        return 20 * info["n"] * max(info["m"] - 1, 0)
+    if op.startswith("knn/"):
+        return 12 * info["n"] + 12 * info["m"] + 8 * info["m"] * info["k"]
     N, M, C, h = info["N"], info["M"], info["C"], info["h"]
     if op == "attn_fwd/A1":
         return 8 * N * C + 4 * M + 4 * N + 4 * M * h
@@ -47,11 +52,6 @@ def algorithmic_bytes(op, info):
         return 12 * M * h
     if op == "attn_bwd":
         return 44 * N * C + 12 * N + 36 * M + 16 * M * h + 16 * M * h  # + A3 backward (y, gy read; gx write) + add
-    if op.startswith("fps/"):
-        # per iteration: read xyz (12 B) + min-dist (4 B) and write min-dist (4 B) for every point
-        return 20 * info["n"] * max(info["m"] - 1, 0)
-    if op.startswith("knn/"):
-        return 12 * info["n"] + 12 * info["m"] + 8 * info["m"] * info["k"]
     return None
 
 

@@ -143,6 +143,7 @@ def cpu_baseline(run):
     the same scene; also the full-size integer parity check of the GPU results."""
     from oracle import index_ref, pointops_ref as ref
     cfg, results, states = run["cfg"], run["results"], run["states"]
+    ref.set_num_threads(ref.host_cores(16))  # a one-GPU box owns 16 host cores; OpenMP would otherwise spawn one thread per visible CPU
     cores = ref.num_threads()
     parity = {}
     t_total = 0.0

@@ -18,7 +18,7 @@
  *
  * PART 2 are the additional native entry points this build adds on the same path (segment softmax
  * = the torch_scatter.scatter_softmax call of the model, CSC transposition used by the backward
- * kernels, the on-device index build, cooperative FPS).
+ * kernels, scratch memory for the bucketed exact FPS).
  */
 #ifndef POINTOPS2_HIP_H
 #define POINTOPS2_HIP_H
@@ -109,9 +109,9 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher(int N, int M, int
 
 /* rpe_v2/relative_pos_encoding_cuda_kernel_v2.h:22-29 — CSR forms.  table [L,h,hdim,3]; rel_idx [M,3].
  * hdim must be 16 or 32.  backward: grad_q / grad_attn fully written; grad_k / grad_v / table grads
- * ACCUMULATE (pre-zeroed by the caller).  The table length L is not part of the reference signature:
- * set it with pointops2_set_table_rows() before a *_backward_* call (default 2*1024 rows is never
- * exceeded by the reference's models; the Python layer always sets it). */
+ * ACCUMULATE (pre-zeroed by the caller).  The table length L is not part of the reference signature
+ * but the kernels stage the tables in LDS: call pointops2_set_table_rows(L) before any *_v3 bias or
+ * *_v2 rel-pos-value launcher (forward and backward); without it the call records an error. */
 void dot_prod_with_idx_forward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max, int T, const float *q,
                                                 const int *index_q, const float *k, const int *index_k,
                                                 const float *table_q, const float *table_k, const int *rel_idx,
@@ -146,6 +146,15 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
 
 /* Rows L of the [L,h,hdim,3] tables for the next *_v2/_v3 rel-pos call on this thread. */
 void pointops2_set_table_rows(int L);
+
+/* Bucketed exact FPS (same index sequence as the reference, ~30x fewer bytes per step): taken by
+ * furthestsampling_cuda_launcher when the caller has lent a scratch buffer of at least
+ * pointops2_fps_workspace_bytes(b, N) bytes with pointops2_set_workspace() and announced the total
+ * point count N = offset[b-1] of the next call with pointops2_set_point_count() (the reference
+ * signature only carries the largest batch element).  Otherwise the single-workgroup scan runs. */
+void pointops2_set_workspace(void *device_ptr, size_t bytes);
+void pointops2_set_point_count(int N);
+size_t pointops2_fps_workspace_bytes(int b, int N);
 
 /* Key-major ("CSC") transposition of a CSR pair list, used by the backward kernels instead of
  * global float atomics.  When set (thread-local, cleared with NULLs), the *_backward_* launchers

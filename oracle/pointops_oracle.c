@@ -38,6 +38,13 @@ static int omp_get_thread_num(void) { return 0; }
 #endif
 
 int oracle_num_threads(void) { return omp_get_max_threads(); }
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* cuda_utils.h:10-13 */
 static int opt_n_threads(int work_size) {

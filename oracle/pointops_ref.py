@@ -49,6 +49,19 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    lib().oracle_set_num_threads(int(n))
+
+
+def host_cores(cap=16):
+    """CPU share of this process (affinity mask), capped: a one-GPU box owns 16 of the host's cores."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, cap))
+
+
 def opt_n_threads(n):
     return int(lib().oracle_opt_n_threads(int(n)))
 

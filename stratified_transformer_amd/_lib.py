@@ -20,6 +20,8 @@ I, U, P, Z = ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t
 SIGNATURES = {
     "pointops2_set_stream": [P],
     "pointops2_set_table_rows": [I],
+    "pointops2_set_workspace": [P, Z],
+    "pointops2_set_point_count": [I],
     "pointops2_set_csc": [P, P, P],
     "pointops2_csc_build": [I, I, P, P, P, P, P, P, Z],
     "furthestsampling_cuda_launcher": [I, I, P, P, P, P, P],
@@ -56,6 +58,7 @@ RESULTS = {
     "pointops2_last_error": ([], ctypes.c_char_p),
     "pointops2_abi_version": ([], I),
     "pointops2_csc_workspace_bytes": ([I, I], Z),
+    "pointops2_fps_workspace_bytes": ([I, I], Z),
 }
 
 

@@ -15,8 +15,13 @@ struct LaunchState {
     const int *csc_offsets = nullptr;
     const int *csc_pair = nullptr;
     const int *csc_query = nullptr;
+    int total_points = 0;  // pointops2_set_point_count: N of the next furthestsampling call (0 = unknown)
 };
 LaunchState &state();
+
+// fps_bucket.hip: returns false when the bucketed path does not apply (no workspace / unknown N)
+bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset,
+                       int N_total, int *idx);
 
 inline void set_error(const char *msg) { state().error = msg; }
 

@@ -1,0 +1,305 @@
+// I1 (fast path): exact furthest point sampling with spatial buckets, gfx950.
+//
+// FPS is m dependent arg-max steps.  The reference (and sampling.hip) rescans the whole cloud in
+// every step: 20*N bytes and ~N/1024 loop trips per step from one workgroup.  Almost all of that
+// work cannot change anything: a point's running min-distance only drops if the new sample is
+// closer to it than its current value.  This kernel keeps the SAME arithmetic and the SAME winner
+// (bit-exact index sequence, including the reference's launch-geometry tie rule, see sampling.hip)
+// but skips, per step, every bucket of points that provably cannot change:
+//
+//   set-up  points of each batch element are sorted along a Morton (z-order) curve and cut into
+//           buckets of BSZ consecutive points (BSZ = 64 for n <= 131072); a bucket has an axis-
+//           aligned box and a cached maximum  key = (min-dist bits << 32 | tie rank)  of its points.
+//   step    (a) every thread tests buckets: lower bound lb of the squared distance from the new
+//               sample to the box, computed with the SAME fma chain as the point distance — every
+//               rounding in that chain is monotone, so lb <= d(sample, p) in fp32 for every p in
+//               the box; if lb >= cached max min-dist, min(d, tmp) == tmp for the whole bucket: skip;
+//           (b) touched buckets go to an LDS work list; one wave per bucket updates its points
+//               (coalesced, L2-resident), re-reduces the bucket key and stores the arg-max's
+//               coordinates next to it;
+//           (c) the global arg-max is a reduction over the <= 2048 bucket keys in LDS; the winner's
+//               coordinates come from LDS too, so a step has no dependent global load besides (b).
+//   Late in the sampling a step touches a handful of buckets (~1 wave pass); the whole sampling is
+//   ~m * 3 workgroup barriers instead of m full-cloud scans.
+//
+// One workgroup per batch element (as the reference): no cross-workgroup synchronisation at all.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace p2 {
+
+struct Workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+Workspace &workspace() {
+    static thread_local Workspace w;
+    return w;
+}
+
+constexpr int FPS_MAX_BUCKETS = 2048;
+constexpr int FPS_BS = 1024;
+
+__device__ __forceinline__ float sqd(float dx, float dy, float dz) {
+    return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+}
+__device__ __forceinline__ unsigned long long wmax64(unsigned long long v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const unsigned long long o = __shfl_xor(v, s, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long key_of(float d2, int rel, int Bref, int log2B) {
+    const unsigned tref = (unsigned)rel & (unsigned)(Bref - 1);
+    const unsigned cidx = (unsigned)rel >> log2B;
+    const unsigned brev = log2B ? (__brev(tref) >> (32 - log2B)) : 0u;
+    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(0x7fffffffu - ((brev << 21) | cidx));
+}
+__device__ __forceinline__ int rel_of(unsigned long long key, int Bref, int log2B) {
+    const unsigned key2 = 0x7fffffffu - (unsigned)(key & 0xffffffffull);
+    const unsigned brev = key2 >> 21, cidx = key2 & ((1u << 21) - 1);
+    const unsigned tref = log2B ? (__brev(brev) >> (32 - log2B)) : 0u;
+    return (int)(cidx * (unsigned)Bref + tref);
+}
+
+// ---- set-up ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fps_bbox_kernel(const float *__restrict__ xyz, const int *__restrict__ offset,
+                                                       float *__restrict__ bbox) {
+    __shared__ float red[6][4];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    const int s = bid == 0 ? 0 : offset[bid - 1], e = offset[bid];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = s + tid; i < e; i += 256)
+        for (int a = 0; a < 3; a++) {
+            const float v = xyz[(size_t)i * 3 + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    for (int a = 0; a < 3; a++) {
+        for (int st = 1; st < 64; st <<= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], st, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], st, 64));
+        }
+        if ((tid & 63) == 0) { red[a][tid >> 6] = mn[a]; red[3 + a][tid >> 6] = mx[a]; }
+    }
+    __syncthreads();
+    if (tid < 3) bbox[bid * 6 + tid] = fminf(fminf(red[tid][0], red[tid][1]), fminf(red[tid][2], red[tid][3]));
+    else if (tid < 6) bbox[bid * 6 + tid] = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
+}
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
+    v &= 0x3ff;
+    v = (v | (v << 16)) & 0x030000ff;
+    v = (v | (v << 8)) & 0x0300f00f;
+    v = (v | (v << 4)) & 0x030c30c3;
+    v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+
+__global__ void fps_morton_kernel(int N, int b, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                  const float *__restrict__ bbox, unsigned long long *__restrict__ keys, int *__restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int bid = 0;
+    while (bid < b - 1 && i >= offset[bid]) bid++;
+    unsigned code = 0;
+    for (int a = 0; a < 3; a++) {
+        const float lo = bbox[bid * 6 + a], hi = bbox[bid * 6 + 3 + a];
+        const float ext = fmaxf(hi - lo, 1e-20f);
+        int c = (int)((xyz[(size_t)i * 3 + a] - lo) / ext * 1024.f);
+        c = min(max(c, 0), 1023);
+        code |= spread10((unsigned)c) << a;
+    }
+    keys[i] = ((unsigned long long)bid << 32) | code;
+    vals[i] = i;
+}
+
+__global__ void fps_gather_kernel(int N, const float *__restrict__ xyz, const int *__restrict__ order,
+                                  float *__restrict__ sx, float *__restrict__ sy, float *__restrict__ sz,
+                                  float *__restrict__ stmp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int o = order[i];
+    sx[i] = xyz[(size_t)o * 3 + 0];
+    sy[i] = xyz[(size_t)o * 3 + 1];
+    sz[i] = xyz[(size_t)o * 3 + 2];
+    stmp[i] = 1e10f;  // pointops.py:26
+}
+
+// ---- sampling --------------------------------------------------------------------------------
+__global__ __launch_bounds__(FPS_BS) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
+                                                            const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                            const float *__restrict__ sx, const float *__restrict__ sy,
+                                                            const float *__restrict__ sz, const int *__restrict__ sorig,
+                                                            float *__restrict__ stmp, int *__restrict__ idx) {
+    constexpr int NW = FPS_BS / 64;
+    extern __shared__ unsigned long long smem64[];
+    unsigned long long *bkey = smem64;                                  // [MAXB]
+    float *bminx = reinterpret_cast<float *>(bkey + FPS_MAX_BUCKETS);  // 6 x [MAXB] box, 3 x [MAXB] arg-max coords
+    float *bminy = bminx + FPS_MAX_BUCKETS, *bminz = bminy + FPS_MAX_BUCKETS;
+    float *bmaxx = bminz + FPS_MAX_BUCKETS, *bmaxy = bmaxx + FPS_MAX_BUCKETS, *bmaxz = bmaxy + FPS_MAX_BUCKETS;
+    float *bestx = bmaxz + FPS_MAX_BUCKETS, *besty = bestx + FPS_MAX_BUCKETS, *bestz = besty + FPS_MAX_BUCKETS;
+    int *worklist = reinterpret_cast<int *>(bestz + FPS_MAX_BUCKETS);  // [MAXB]
+    __shared__ unsigned long long wred[NW];
+    __shared__ float wcoord[NW][3];
+    __shared__ int wl_count;
+
+    const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
+    const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
+    if (end_n <= start_n) {
+        for (int j = start_m + tid; j < end_m; j += FPS_BS) idx[j] = start_n;
+        return;
+    }
+    const int n = end_n - start_n;
+    const int nb = (n + BSZ - 1) / BSZ;
+
+    // bucket boxes; keys start at "min-dist 1e10" so the first step touches every bucket
+    for (int bk = wave; bk < nb; bk += NW) {
+        const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
+        float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
+        for (int pos = p0 + lane; pos < p1; pos += 64) {
+            const float x = sx[pos], y = sy[pos], z = sz[pos];
+            mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
+            mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
+        }
+        for (int st = 1; st < 64; st <<= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, st, 64)); mny = fminf(mny, __shfl_xor(mny, st, 64)); mnz = fminf(mnz, __shfl_xor(mnz, st, 64));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, st, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, st, 64)); mxz = fmaxf(mxz, __shfl_xor(mxz, st, 64));
+        }
+        if (lane == 0) {
+            bminx[bk] = mnx; bminy[bk] = mny; bminz[bk] = mnz;
+            bmaxx[bk] = mxx; bmaxy[bk] = mxy; bmaxz[bk] = mxz;
+            bkey[bk] = (unsigned long long)__float_as_uint(1e10f) << 32;
+        }
+    }
+    if (tid == 0) {
+        wl_count = 0;
+        if (start_m < end_m) idx[start_m] = start_n;
+    }
+    float x1 = xyz[(size_t)start_n * 3 + 0], y1 = xyz[(size_t)start_n * 3 + 1], z1 = xyz[(size_t)start_n * 3 + 2];
+    __syncthreads();
+
+    for (int j = start_m + 1; j < end_m; j++) {
+        // (a) which buckets can change?
+        for (int bk = tid; bk < nb; bk += FPS_BS) {
+            const float dx = fmaxf(fmaxf(bminx[bk] - x1, x1 - bmaxx[bk]), 0.f);
+            const float dy = fmaxf(fmaxf(bminy[bk] - y1, y1 - bmaxy[bk]), 0.f);
+            const float dz = fmaxf(fmaxf(bminz[bk] - z1, z1 - bmaxz[bk]), 0.f);
+            const float lb = sqd(dx, dy, dz);
+            const float bmaxd = __uint_as_float((unsigned)(bkey[bk] >> 32));
+            if (lb < bmaxd) worklist[atomicAdd(&wl_count, 1)] = bk;
+        }
+        __syncthreads();
+        const int cnt = wl_count;
+        // (b) update touched buckets, one wave each
+        for (int w = wave; w < cnt; w += NW) {
+            const int bk = worklist[w];
+            const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
+            unsigned long long best = 0ull;
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            for (int pos = p0 + lane; pos < p1; pos += 64) {
+                const float x = sx[pos], y = sy[pos], z = sz[pos], t = stmp[pos];
+                const float d = sqd(x - x1, y - y1, z - z1);
+                const float d2 = fminf(d, t);
+                if (d2 != t) stmp[pos] = d2;
+                const unsigned long long key = key_of(d2, sorig[pos] - start_n, Bref, log2B);
+                if (key > best) { best = key; bx = x; by = y; bz = z; }
+            }
+            const unsigned long long wm = wmax64(best);
+            if (best == wm && best != 0ull) {  // keys are unique: exactly one lane
+                bkey[bk] = wm;
+                bestx[bk] = bx; besty[bk] = by; bestz[bk] = bz;
+            }
+        }
+        __syncthreads();
+        // (c) arg-max over bucket keys
+        unsigned long long my = 0ull;
+        int mybk = 0;
+        for (int bk = tid; bk < nb; bk += FPS_BS) {
+            const unsigned long long kk = bkey[bk];
+            if (kk > my) { my = kk; mybk = bk; }
+        }
+        const unsigned long long wm = wmax64(my);
+        if (my == wm && my != 0ull) {
+            wred[wave] = wm;
+            wcoord[wave][0] = bestx[mybk]; wcoord[wave][1] = besty[mybk]; wcoord[wave][2] = bestz[mybk];
+        } else if (wm == 0ull && lane == 0) {
+            wred[wave] = 0ull;
+        }
+        if (tid == 0) wl_count = 0;
+        __syncthreads();
+        unsigned long long v = lane < NW ? wred[lane] : 0ull;
+        const unsigned long long vm = wmax64(v);
+        const int src = __ffsll((unsigned long long)__ballot(v == vm && lane < NW)) - 1;
+        x1 = wcoord[src][0]; y1 = wcoord[src][1]; z1 = wcoord[src][2];
+        if (tid == 0) idx[j] = start_n + rel_of(vm, Bref, log2B);
+    }
+}
+
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+static int bits_for(int b) {
+    int r = 1;
+    while ((1 << r) < b) r++;
+    return r;
+}
+static size_t fps_cub_bytes(int b, int N) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                             (const int *)nullptr, (int *)nullptr, N, 0, 32 + bits_for(b), (hipStream_t) nullptr);
+    return bytes;
+}
+
+// returns false when the bucket path does not apply (caller falls back to the block kernel)
+bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset,
+                       int N_total, int *idx) {
+    Workspace &w = workspace();
+    if (w.ptr == nullptr || N_total <= 0) return false;
+    const size_t need = pointops2_fps_workspace_bytes(b, N_total);
+    if (w.bytes < need) return false;
+    hipStream_t st = state().stream;
+    char *p = reinterpret_cast<char *>(w.ptr);
+    const size_t f4 = al((size_t)N_total * 4), f8 = al((size_t)N_total * 8);
+    float *sx = (float *)p; p += f4;
+    float *sy = (float *)p; p += f4;
+    float *sz = (float *)p; p += f4;
+    float *stmp = (float *)p; p += f4;
+    int *sorig = (int *)p; p += f4;
+    int *vals_in = (int *)p; p += f4;
+    unsigned long long *keys_in = (unsigned long long *)p; p += f8;
+    unsigned long long *keys_out = (unsigned long long *)p; p += f8;
+    float *bbox = (float *)p; p += al((size_t)b * 6 * 4);
+    void *cub_tmp = p;
+    size_t cub_bytes = w.bytes - (size_t)(p - reinterpret_cast<char *>(w.ptr));
+    hipLaunchKernelGGL(fps_bbox_kernel, dim3(b), dim3(256), 0, st, xyz, offset, bbox);
+    hipLaunchKernelGGL(fps_morton_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, b, xyz, offset, bbox, keys_in, vals_in);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys_in, keys_out, (const int *)vals_in, sorig, N_total, 0,
+                                                      32 + bits_for(b), st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return true; }
+    hipLaunchKernelGGL(fps_gather_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, xyz, sorig, sx, sy, sz, stmp);
+    const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);
+    const size_t lds = (size_t)FPS_MAX_BUCKETS * (8 + 9 * 4 + 4);
+    allow_big_lds(fps_bucket_kernel, lds);
+    hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FPS_BS), lds, st, Bref, log2B, BSZ, xyz, offset, new_offset, sx, sy, sz, sorig, stmp, idx);
+    return true;
+}
+
+}  // namespace p2
+
+using namespace p2;
+
+extern "C" {
+
+void pointops2_set_workspace(void *ptr, size_t bytes) {
+    workspace().ptr = ptr;
+    workspace().bytes = bytes;
+}
+
+size_t pointops2_fps_workspace_bytes(int b, int N) {
+    if (b <= 0 || N <= 0) return 0;
+    return 6 * al((size_t)N * 4) + 2 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al(fps_cub_bytes(b, N));
+}
+
+}  // extern "C"

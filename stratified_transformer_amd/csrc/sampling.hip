@@ -110,6 +110,13 @@ void furthestsampling_cuda_launcher(int b, int n, const float *xyz, const int *o
     int log2B = 0;
     while ((1 << log2B) < Bref) log2B++;
     hipStream_t st = state().stream;
+    const int N_total = state().total_points;
+    state().total_points = 0;
+    // bucketed exact FPS (fps_bucket.hip) needs a caller-provided workspace and the total point count
+    if (n >= 2048 && fps_bucket_launch(b, n, Bref, log2B, xyz, offset, new_offset, N_total, idx)) {
+        check_launch();
+        return;
+    }
     if (n > 4096)
         hipLaunchKernelGGL(fps_block_kernel<1024>, dim3(b), dim3(1024), 0, st, Bref, log2B, xyz, offset, new_offset, tmp, idx);
     else

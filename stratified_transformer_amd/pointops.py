@@ -115,8 +115,17 @@ class FurthestSampling(Function):
             n_max = max(offs[i] - offs[i - 1], n_max)
         idx = _zeros(new_offs[b - 1], xyz, torch.int32)
         tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
-        pointops_cuda.furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx)
-        del tmp
+        # lend the library scratch memory for the bucketed exact FPS (csrc/fps_bucket.hip); the
+        # reference signature carries neither a workspace nor the total point count
+        l = _lib.lib()
+        ws = torch.empty(int(l.pointops2_fps_workspace_bytes(b, n)), dtype=torch.uint8, device=xyz.device)
+        l.pointops2_set_workspace(ptr(ws), ws.numel())
+        l.pointops2_set_point_count(n)
+        try:
+            pointops_cuda.furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx)
+        finally:
+            l.pointops2_set_workspace(None, 0)
+        del tmp, ws
         return idx
 
 

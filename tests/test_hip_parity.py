@@ -232,6 +232,26 @@ def test_fps_bit_exact_with_exact_ties(P):
     for n, m in ((len(g), 300), (700, 700), (100, 40), (5, 5), (1, 1)):
         got = _fps(P, g[:n], [n], [m])
         assert np.array_equal(got, ref.furthestsampling(g[:n], np.array([n], np.int32), np.array([m], np.int32))), (n, m)
+    # a lattice large enough for the bucketed kernel (n >= 2048), sampled to exhaustion and beyond
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    g = g[np.random.default_rng(2).permutation(len(g))]
+    for offset, new_offset in (([3072], [3072]), ([3072], [3100]), ([1000, 3072], [400, 1300])):
+        got = _fps(P, g, offset, new_offset)
+        assert np.array_equal(got, ref.furthestsampling(g, np.asarray(offset, np.int32), np.asarray(new_offset, np.int32))), offset
+
+
+def test_fps_block_kernel_fallback_matches_bucketed(P):
+    """Without a lent workspace the launcher runs the single-workgroup scan: same indices."""
+    from stratified_transformer_amd import _lib, pointops2_cuda
+    rng = np.random.default_rng(8)
+    xyz = rng.random((5000, 3), dtype=np.float32)
+    off, noff = dev(np.array([5000], np.int32)), dev(np.array([626], np.int32))
+    idx = torch.zeros(626, dtype=torch.int32, device="cuda")
+    tmp = torch.full((5000,), 1e10, device="cuda")
+    _lib.lib().pointops2_set_workspace(None, 0)
+    pointops2_cuda.furthestsampling_cuda(1, 5000, dev(xyz), off, noff, tmp, idx)
+    assert np.array_equal(_np(idx), _fps(P, xyz, [5000], [626]))
+    assert np.array_equal(_np(idx), ref.furthestsampling(xyz, np.array([5000], np.int32), np.array([626], np.int32)))
 
 
 def test_fps_scene_sizes(P):

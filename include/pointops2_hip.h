@@ -155,6 +155,12 @@ void pointops2_set_table_rows(int L);
 void pointops2_set_workspace(void *device_ptr, size_t bytes);
 void pointops2_set_point_count(int N);
 size_t pointops2_fps_workspace_bytes(int b, int N);
+/* FPS is deterministic, so a request for fewer samples of the same cloud is a prefix of a longer one
+ * (the model asks for n/8+1 and then n/4+1 samples of the same points, stratified_transformer.py:289,103).
+ * If the workspace still holds the state of the previous call on the SAME xyz/offset, pass that call's
+ * idx/new_offset here: the next furthestsampling_cuda_launcher copies those samples and continues
+ * instead of starting over.  One-shot (cleared by the launch). */
+void pointops2_set_fps_resume(const int *prev_idx, const int *prev_new_offset);
 
 /* Key-major ("CSC") transposition of a CSR pair list, used by the backward kernels instead of
  * global float atomics.  When set (thread-local, cleared with NULLs), the *_backward_* launchers

@@ -22,6 +22,7 @@ SIGNATURES = {
     "pointops2_set_table_rows": [I],
     "pointops2_set_workspace": [P, Z],
     "pointops2_set_point_count": [I],
+    "pointops2_set_fps_resume": [P, P],
     "pointops2_set_csc": [P, P, P],
     "pointops2_csc_build": [I, I, P, P, P, P, P, P, Z],
     "furthestsampling_cuda_launcher": [I, I, P, P, P, P, P],

@@ -34,14 +34,18 @@ inline bool check_launch() {
     return true;
 }
 
+inline void set_error(const char *msg);
 constexpr int WAVE = 64;
 constexpr int kNumCU = 256;  // MI355X
 
 // Dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (gfx950: 160 KiB per CU).
 template <typename K>
 inline void allow_big_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // the attribute bounds dynamic + static LDS together: ask for what this launch needs, not the 160 KiB cap
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) set_error(hipGetErrorString(e));
+    }
 }
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }

@@ -43,13 +43,28 @@ constexpr int FPS_BS = 1024;
 __device__ __forceinline__ float sqd(float dx, float dy, float dz) {
     return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
 }
+// wave-wide unsigned max with DPP row operations (6 VALU + 1 readlane; a __shfl_xor butterfly costs 6
+// dependent ds_bpermute round trips, and the 64-bit key would double that)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_step(unsigned v) {
+    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return v > t ? v : t;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = dpp_step<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_step<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_step<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_step<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row max
+    v = dpp_step<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
+    v = dpp_step<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3: lane 63 holds the wave max
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// max of (hi:lo) keys: max hi first, then max lo among the lanes that hold it
 __device__ __forceinline__ unsigned long long wmax64(unsigned long long v) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const unsigned long long o = __shfl_xor(v, s, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mh = wave_max_u32(hi);
+    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
 }
 __device__ __forceinline__ unsigned long long key_of(float d2, int rel, int Bref, int log2B) {
     const unsigned tref = (unsigned)rel & (unsigned)(Bref - 1);
@@ -116,24 +131,27 @@ __global__ void fps_morton_kernel(int N, int b, const float *__restrict__ xyz, c
     vals[i] = i;
 }
 
-__global__ void fps_gather_kernel(int N, const float *__restrict__ xyz, const int *__restrict__ order,
-                                  float *__restrict__ sx, float *__restrict__ sy, float *__restrict__ sz,
-                                  float *__restrict__ stmp) {
+// sorted-order point records: (x, y, z, running min-dist) as one 16-byte load, plus the 31-bit tie rank
+__global__ void fps_gather_kernel(int N, int b, int Bref, int log2B, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                  const int *__restrict__ order, float4 *__restrict__ pts, unsigned *__restrict__ rank) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int o = order[i];
-    sx[i] = xyz[(size_t)o * 3 + 0];
-    sy[i] = xyz[(size_t)o * 3 + 1];
-    sz[i] = xyz[(size_t)o * 3 + 2];
-    stmp[i] = 1e10f;  // pointops.py:26
+    pts[i] = make_float4(xyz[(size_t)o * 3 + 0], xyz[(size_t)o * 3 + 1], xyz[(size_t)o * 3 + 2], 1e10f);  // pointops.py:26
+    int bid = 0;
+    while (bid < b - 1 && i >= offset[bid]) bid++;
+    const int start_n = bid == 0 ? 0 : offset[bid - 1];
+    rank[i] = (unsigned)key_of(0.f, o - start_n, Bref, log2B);
 }
 
 // ---- sampling --------------------------------------------------------------------------------
+// prev_idx/prev_offset (optional): samples already computed on this workspace by an earlier call for the
+// same cloud (FPS is deterministic: a shorter request is a prefix of a longer one) — copied, then resumed.
 __global__ __launch_bounds__(FPS_BS) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
                                                             const int *__restrict__ offset, const int *__restrict__ new_offset,
-                                                            const float *__restrict__ sx, const float *__restrict__ sy,
-                                                            const float *__restrict__ sz, const int *__restrict__ sorig,
-                                                            float *__restrict__ stmp, int *__restrict__ idx) {
+                                                            float4 *__restrict__ pts, const unsigned *__restrict__ rank,
+                                                            const int *__restrict__ prev_idx, const int *__restrict__ prev_offset,
+                                                            int *__restrict__ idx) {
     constexpr int NW = FPS_BS / 64;
     extern __shared__ unsigned long long smem64[];
     unsigned long long *bkey = smem64;                                  // [MAXB]
@@ -156,33 +174,52 @@ __global__ __launch_bounds__(FPS_BS) void fps_bucket_kernel(int Bref, int log2B,
     const int n = end_n - start_n;
     const int nb = (n + BSZ - 1) / BSZ;
 
-    // bucket boxes; keys start at "min-dist 1e10" so the first step touches every bucket
+    // samples inherited from the previous call on this state
+    int done = 0;
+    if (prev_idx) {
+        const int ps = bid == 0 ? 0 : prev_offset[bid - 1], pe = prev_offset[bid];
+        done = min(pe - ps, end_m - start_m);
+        for (int t = tid; t < done; t += FPS_BS) idx[start_m + t] = prev_idx[ps + t];
+    }
+    if (start_m + done >= end_m) return;
+
+    // bucket boxes and cached keys from the current min-dist field (1e10 everywhere on a fresh start,
+    // so the first step touches every bucket)
     for (int bk = wave; bk < nb; bk += NW) {
         const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
         float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
+        unsigned long long best = 0ull;
+        float bx = 0.f, by = 0.f, bz = 0.f;
         for (int pos = p0 + lane; pos < p1; pos += 64) {
-            const float x = sx[pos], y = sy[pos], z = sz[pos];
-            mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
-            mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
+            const float4 p = pts[pos];
+            mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
+            mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(p.w) << 32) | rank[pos];
+            if (key > best) { best = key; bx = p.x; by = p.y; bz = p.z; }
         }
         for (int st = 1; st < 64; st <<= 1) {
             mnx = fminf(mnx, __shfl_xor(mnx, st, 64)); mny = fminf(mny, __shfl_xor(mny, st, 64)); mnz = fminf(mnz, __shfl_xor(mnz, st, 64));
             mxx = fmaxf(mxx, __shfl_xor(mxx, st, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, st, 64)); mxz = fmaxf(mxz, __shfl_xor(mxz, st, 64));
         }
+        const unsigned long long wm = wmax64(best);
         if (lane == 0) {
             bminx[bk] = mnx; bminy[bk] = mny; bminz[bk] = mnz;
             bmaxx[bk] = mxx; bmaxy[bk] = mxy; bmaxz[bk] = mxz;
-            bkey[bk] = (unsigned long long)__float_as_uint(1e10f) << 32;
+        }
+        if (best == wm && best != 0ull) {
+            bkey[bk] = wm;
+            bestx[bk] = bx; besty[bk] = by; bestz[bk] = bz;
         }
     }
     if (tid == 0) {
         wl_count = 0;
-        if (start_m < end_m) idx[start_m] = start_n;
+        if (done == 0) idx[start_m] = start_n;
     }
-    float x1 = xyz[(size_t)start_n * 3 + 0], y1 = xyz[(size_t)start_n * 3 + 1], z1 = xyz[(size_t)start_n * 3 + 2];
-    __syncthreads();
+    __syncthreads();  // also orders the idx[] copy above before the read below
+    const int first = done == 0 ? start_n : idx[start_m + done - 1];
+    float x1 = xyz[(size_t)first * 3 + 0], y1 = xyz[(size_t)first * 3 + 1], z1 = xyz[(size_t)first * 3 + 2];
 
-    for (int j = start_m + 1; j < end_m; j++) {
+    for (int j = start_m + max(done, 1); j < end_m; j++) {
         // (a) which buckets can change?
         for (int bk = tid; bk < nb; bk += FPS_BS) {
             const float dx = fmaxf(fmaxf(bminx[bk] - x1, x1 - bmaxx[bk]), 0.f);
@@ -201,12 +238,13 @@ __global__ __launch_bounds__(FPS_BS) void fps_bucket_kernel(int Bref, int log2B,
             unsigned long long best = 0ull;
             float bx = 0.f, by = 0.f, bz = 0.f;
             for (int pos = p0 + lane; pos < p1; pos += 64) {
-                const float x = sx[pos], y = sy[pos], z = sz[pos], t = stmp[pos];
-                const float d = sqd(x - x1, y - y1, z - z1);
-                const float d2 = fminf(d, t);
-                if (d2 != t) stmp[pos] = d2;
-                const unsigned long long key = key_of(d2, sorig[pos] - start_n, Bref, log2B);
-                if (key > best) { best = key; bx = x; by = y; bz = z; }
+                const float4 p = pts[pos];
+                const unsigned rk = rank[pos];
+                const float d = sqd(p.x - x1, p.y - y1, p.z - z1);
+                const float d2 = fminf(d, p.w);
+                if (d2 != p.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | rk;
+                if (key > best) { best = key; bx = p.x; by = p.y; bz = p.z; }
             }
             const unsigned long long wm = wmax64(best);
             if (best == wm && best != 0ull) {  // keys are unique: exactly one lane
@@ -252,6 +290,15 @@ static size_t fps_cub_bytes(int b, int N) {
     return bytes;
 }
 
+struct FpsResume {
+    const int *prev_idx = nullptr;
+    const int *prev_offset = nullptr;
+};
+FpsResume &fps_resume() {
+    static thread_local FpsResume r;
+    return r;
+}
+
 // returns false when the bucket path does not apply (caller falls back to the block kernel)
 bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset,
                        int N_total, int *idx) {
@@ -261,11 +308,11 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     if (w.bytes < need) return false;
     hipStream_t st = state().stream;
     char *p = reinterpret_cast<char *>(w.ptr);
-    const size_t f4 = al((size_t)N_total * 4), f8 = al((size_t)N_total * 8);
-    float *sx = (float *)p; p += f4;
-    float *sy = (float *)p; p += f4;
-    float *sz = (float *)p; p += f4;
-    float *stmp = (float *)p; p += f4;
+    const size_t f4 = al((size_t)N_total * 4), f8 = al((size_t)N_total * 8), f16 = al((size_t)N_total * 16);
+    // persistent part of the workspace (what a resumed call needs)
+    float4 *pts = (float4 *)p; p += f16;
+    unsigned *rank = (unsigned *)p; p += f4;
+    // set-up scratch
     int *sorig = (int *)p; p += f4;
     int *vals_in = (int *)p; p += f4;
     unsigned long long *keys_in = (unsigned long long *)p; p += f8;
@@ -273,16 +320,21 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     float *bbox = (float *)p; p += al((size_t)b * 6 * 4);
     void *cub_tmp = p;
     size_t cub_bytes = w.bytes - (size_t)(p - reinterpret_cast<char *>(w.ptr));
-    hipLaunchKernelGGL(fps_bbox_kernel, dim3(b), dim3(256), 0, st, xyz, offset, bbox);
-    hipLaunchKernelGGL(fps_morton_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, b, xyz, offset, bbox, keys_in, vals_in);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys_in, keys_out, (const int *)vals_in, sorig, N_total, 0,
-                                                      32 + bits_for(b), st);
-    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return true; }
-    hipLaunchKernelGGL(fps_gather_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, xyz, sorig, sx, sy, sz, stmp);
+    FpsResume rs = fps_resume();
+    fps_resume() = FpsResume();
+    if (rs.prev_idx == nullptr) {
+        hipLaunchKernelGGL(fps_bbox_kernel, dim3(b), dim3(256), 0, st, xyz, offset, bbox);
+        hipLaunchKernelGGL(fps_morton_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, b, xyz, offset, bbox, keys_in, vals_in);
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys_in, keys_out, (const int *)vals_in, sorig, N_total, 0,
+                                                          32 + bits_for(b), st);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return true; }
+        hipLaunchKernelGGL(fps_gather_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, b, Bref, log2B, xyz, offset, sorig, pts, rank);
+    }
     const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);
     const size_t lds = (size_t)FPS_MAX_BUCKETS * (8 + 9 * 4 + 4);
     allow_big_lds(fps_bucket_kernel, lds);
-    hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FPS_BS), lds, st, Bref, log2B, BSZ, xyz, offset, new_offset, sx, sy, sz, sorig, stmp, idx);
+    hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FPS_BS), lds, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
+                       rs.prev_idx, rs.prev_offset, idx);
     return true;
 }
 
@@ -299,7 +351,12 @@ void pointops2_set_workspace(void *ptr, size_t bytes) {
 
 size_t pointops2_fps_workspace_bytes(int b, int N) {
     if (b <= 0 || N <= 0) return 0;
-    return 6 * al((size_t)N * 4) + 2 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al(fps_cub_bytes(b, N));
+    return al((size_t)N * 16) + 3 * al((size_t)N * 4) + 2 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al(fps_cub_bytes(b, N));
+}
+
+void pointops2_set_fps_resume(const int *prev_idx, const int *prev_offset) {
+    fps_resume().prev_idx = prev_idx;
+    fps_resume().prev_offset = prev_offset;
 }
 
 }  // extern "C"

@@ -16,74 +16,9 @@
 //    with global atomics — the reference issues 6-8 global atomics per (pair, channel) into a
 //    9216-float table.  Key-side gradients are produced by key through the CSC view
 //    (pointops2_set_csc); without it the by-query kernel falls back to global atomics.
-#include "common.h"
+#include "rpe_common.h"
 
 namespace p2 {
-
-constexpr size_t kLdsBudget = 72 * 1024;  // two workgroups per CU
-
-// LDS image of one table slice: [hg][3][L][D]
-template <int D>
-__device__ __forceinline__ void stage_table(float *lds, const float *__restrict__ tab, int L, int h, int h0, int hgn) {
-    const int total = hgn * 3 * L * D;
-    for (int x = threadIdx.x; x < total; x += blockDim.x) {
-        const int i = x % D;
-        const int r = (x / D) % L;
-        const int ax = (x / (D * L)) % 3;
-        const int t = x / (D * L * 3);
-        lds[x] = tab[(((size_t)r * h + (h0 + t)) * D + i) * 3 + ax];
-    }
-}
-template <int D>
-__device__ __forceinline__ void zero_lds(float *lds, int n) {
-    for (int x = threadIdx.x; x < n; x += blockDim.x) lds[x] = 0.f;
-}
-// adds the LDS gradient image back into the global [L,h,D,3] table
-template <int D>
-__device__ __forceinline__ void flush_table(const float *lds, float *__restrict__ gtab, int L, int h, int h0, int hgn) {
-    const int total = hgn * 3 * L * D;
-    for (int x = threadIdx.x; x < total; x += blockDim.x) {
-        const float v = lds[x];
-        if (v != 0.f) {
-            const int i = x % D;
-            const int r = (x / D) % L;
-            const int ax = (x / (D * L)) % 3;
-            const int t = x / (D * L * 3);
-            atomicAdd(gtab + (((size_t)r * h + (h0 + t)) * D + i) * 3 + ax, v);
-        }
-    }
-}
-
-template <int D>
-__device__ __forceinline__ const float4 *trow(const float *lds, int L, int t, int ax, int r, int c) {
-    return reinterpret_cast<const float4 *>(lds + (((size_t)t * 3 + ax) * L + r) * D + 4 * c);
-}
-// T(m, head t)[4c..4c+3] = tab[r0,.,.,0] + tab[r1,.,.,1] + tab[r2,.,.,2]   (left to right, as the reference)
-template <int D>
-__device__ __forceinline__ float4 tsum(const float *lds, int L, int t, int r0, int r1, int r2, int c) {
-    return add4(add4(*trow<D>(lds, L, t, 0, r0, c), *trow<D>(lds, L, t, 1, r1, c)), *trow<D>(lds, L, t, 2, r2, c));
-}
-template <int D>
-__device__ __forceinline__ void tadd(float *lds, int L, int t, int r0, int r1, int r2, int c, float4 v) {
-    float *a0 = lds + (((size_t)t * 3 + 0) * L + r0) * D + 4 * c;
-    float *a1 = lds + (((size_t)t * 3 + 1) * L + r1) * D + 4 * c;
-    float *a2 = lds + (((size_t)t * 3 + 2) * L + r2) * D + 4 * c;
-    atomicAdd(a0 + 0, v.x); atomicAdd(a0 + 1, v.y); atomicAdd(a0 + 2, v.z); atomicAdd(a0 + 3, v.w);
-    atomicAdd(a1 + 0, v.x); atomicAdd(a1 + 1, v.y); atomicAdd(a1 + 2, v.z); atomicAdd(a1 + 3, v.w);
-    atomicAdd(a2 + 0, v.x); atomicAdd(a2 + 1, v.y); atomicAdd(a2 + 2, v.z); atomicAdd(a2 + 3, v.w);
-}
-__device__ __forceinline__ int clampr(int r, int L) { return min(max(r, 0), L - 1); }
-
-#define P2_WALK_PROLOGUE                                                            \
-    constexpr int LPG = Geo<D>::LPG, PPW = Geo<D>::PPW;                             \
-    extern __shared__ float lds[];                                                  \
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                     \
-    const int C = h * D;                                                            \
-    const int p = lane / LPG, c = lane % LPG;                                       \
-    const int h0 = blockIdx.y * HG;                                                 \
-    const int hgn = min(HG, h - h0);                                                \
-    const int tsz = hgn * 3 * L * D;                                                \
-    (void)PPW; (void)p; (void)tsz; (void)C; (void)c; (void)wave;
 
 // ------------------------------------------------------------------------------------------------
 // A2 forward: out[m,hh] = sum_i q[query,hh,i]*Tq(m,hh,i) + k[idx_k[m],hh,i]*Tk(m,hh,i)
@@ -530,6 +465,12 @@ void dot_prod_with_idx_backward_cuda_launcher_v3(int N, int M, int h, int hdim, 
     hipStream_t st = state().stream;
     const LaunchState &ls = state();
     const int *co = ls.csc_offsets, *cp = ls.csc_pair;
+    // D=16, L<=80 with a CSC view: table gradients on the matrix cores (rpe_bwd_mfma.hip)
+    if (a2_bwd_mfma(N, h, hdim, L, grad_out, q, index_q_offsets, k, table_q, table_k, rel_idx, co, cp, grad_q, grad_k,
+                    grad_table_q, grad_table_k)) {
+        check_launch();
+        return;
+    }
 #define P2_A2_BWD(D_)                                                                                                       \
     if (co) {                                                                                                               \
         P2_LAUNCH_HG(D_, 2, {                                                                                               \
@@ -591,6 +532,11 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
     hipStream_t st = state().stream;
     const LaunchState &ls = state();
     const int *co = ls.csc_offsets, *cp = ls.csc_pair, *cq = ls.csc_query;
+    if (co && a4_bwd_mfma(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_table)) {
+        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(div_up(N, 4)), dim3(256), 0, st, N, h, co, cq, cp, attn, grad_out, grad_v);
+        check_launch();
+        return;
+    }
 #define P2_A4_BWD(D_)                                                                                                       \
     P2_LAUNCH_HG(D_, 2, {                                                                                                   \
         allow_big_lds(a4_bwd_query_kernel<Dc, HGc, false>, lds_bytes);                                                      \

@@ -146,6 +146,9 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0):
     """Runs the whole unit once.  `states` (list of StageState) carries the resident synthetic tensors;
     pass None on the first call to have them created (not timed by bench.py).  Returns (states, results)."""
     timer = timer or Timer(False)
+    # nothing is carried over from an earlier pass: the CSC transpositions and the FPS sampler state are
+    # rebuilt inside every pass (they are reused only WITHIN a pass, between blocks / the two FPS calls of a stage)
+    P.clear_caches()
     offset_host = [int(o) for o in offset.tolist()]
     make = states is None
     states = [] if make else states

@@ -335,3 +335,24 @@ def test_scatter_softmax_shim_on_gpu(P, golden):
     perm = torch.randperm(src.shape[0], device="cuda")
     y2 = scatter_softmax(src.detach()[perm], dev(golden["blk0_index_0"]).long()[perm], dim=0)
     np.testing.assert_allclose(_np(y2), golden["op_a3_out"][_np(perm)], **TOL)
+
+
+def test_fps_prefix_reuse_and_resume(P):
+    """The sampler state kept between calls: shorter request = prefix, longer request = resumed, and both
+    equal a from-scratch run (and the oracle)."""
+    rng = np.random.default_rng(12)
+    xyz = rng.random((7000, 3), dtype=np.float32)
+    x = dev(xyz)
+    off = dev(np.array([3000, 7000], np.int32))
+    full = ref.furthestsampling(xyz, np.array([3000, 7000], np.int32), np.array([751, 1752], np.int32))
+    P.clear_caches()
+    a = _np(P.furthestsampling(x, off, dev(np.array([376, 877], np.int32))))           # n/8+1 per batch element
+    b = _np(P.furthestsampling(x, off, dev(np.array([751, 1752], np.int32))))          # resumed to n/4+1
+    c = _np(P.furthestsampling(x, off, dev(np.array([100, 300], np.int32))))           # served as a prefix
+    d = _np(P.furthestsampling(x, off, dev(np.array([800, 1000], np.int32))))          # mixed: recomputed
+    assert np.array_equal(b, full)
+    assert np.array_equal(a, np.concatenate([full[:376], full[751:751 + 501]]))
+    assert np.array_equal(c, np.concatenate([full[:100], full[751:751 + 200]]))
+    assert np.array_equal(d, ref.furthestsampling(xyz, np.array([3000, 7000], np.int32), np.array([800, 1000], np.int32)))
+    P.clear_caches()
+    assert np.array_equal(_np(P.furthestsampling(x, off, dev(np.array([751, 1752], np.int32)))), full)

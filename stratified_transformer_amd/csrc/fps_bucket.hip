@@ -38,7 +38,6 @@ Workspace &workspace() {
 }
 
 constexpr int FPS_MAX_BUCKETS = 2048;
-constexpr int FPS_BS = 1024;
 
 __device__ __forceinline__ float sqd(float dx, float dy, float dz) {
     return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
@@ -145,14 +144,48 @@ __global__ void fps_gather_kernel(int N, int b, int Bref, int log2B, const float
 }
 
 // ---- sampling --------------------------------------------------------------------------------
+// Two-level hierarchy: buckets of BSZ points, super-buckets of 32 consecutive buckets (<= 64 supers, one
+// per lane).  Four waves (one per SIMD, so no wave shares a SIMD's issue slots); per step:
+//   S1  every wave (redundantly, no barrier): lane s tests super box s          -> 64-bit touched mask
+//   S2  wave w takes the touched supers with ordinal = w mod 4, tests their 32 buckets, appends the
+//       touched buckets to an LDS work list                                      -> barrier
+//   S3  waves update touched buckets, three per wave in flight (loads batched)   -> barrier
+//   S4  waves recompute the key of the supers they own in this step              -> barrier
+//   S5  every wave (redundantly): arg-max over the <= 64 super keys, winner coordinates from LDS
 // prev_idx/prev_offset (optional): samples already computed on this workspace by an earlier call for the
 // same cloud (FPS is deterministic: a shorter request is a prefix of a longer one) — copied, then resumed.
-__global__ __launch_bounds__(FPS_BS) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
-                                                            const int *__restrict__ offset, const int *__restrict__ new_offset,
-                                                            float4 *__restrict__ pts, const unsigned *__restrict__ rank,
-                                                            const int *__restrict__ prev_idx, const int *__restrict__ prev_offset,
-                                                            int *__restrict__ idx) {
-    constexpr int NW = FPS_BS / 64;
+constexpr int FPS_SUPER = 32;                                 // buckets per super-bucket
+constexpr int FPS_MAX_SUPERS = FPS_MAX_BUCKETS / FPS_SUPER;   // 64
+constexpr int FPS_NW = 4;
+
+struct KeyMax {
+    unsigned long long key;  // wave maximum
+    int lane;                // a lane holding it (unique when keys are unique)
+};
+// 64-bit wave max: DPP max of the high words; the low words only need a second pass when several lanes
+// share the maximal high word (exact distance ties).
+__device__ __forceinline__ KeyMax wave_key_max(unsigned long long v) {
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mh = wave_max_u32(hi);
+    const unsigned long long tied = __ballot(hi == mh);
+    KeyMax r;
+    if (__popcll(tied) == 1) {
+        r.lane = __ffsll(tied) - 1;
+        r.key = ((unsigned long long)mh << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, r.lane);
+    } else {
+        const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+        r.key = ((unsigned long long)mh << 32) | ml;
+        r.lane = __ffsll((unsigned long long)__ballot(hi == mh && lo == ml)) - 1;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(FPS_NW * 64) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
+                                                                 const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                                 float4 *__restrict__ pts, const unsigned *__restrict__ rank,
+                                                                 const int *__restrict__ prev_idx, const int *__restrict__ prev_offset,
+                                                                 int *__restrict__ idx) {
+    constexpr int NT = FPS_NW * 64;
     extern __shared__ unsigned long long smem64[];
     unsigned long long *bkey = smem64;                                  // [MAXB]
     float *bminx = reinterpret_cast<float *>(bkey + FPS_MAX_BUCKETS);  // 6 x [MAXB] box, 3 x [MAXB] arg-max coords
@@ -160,32 +193,34 @@ __global__ __launch_bounds__(FPS_BS) void fps_bucket_kernel(int Bref, int log2B,
     float *bmaxx = bminz + FPS_MAX_BUCKETS, *bmaxy = bmaxx + FPS_MAX_BUCKETS, *bmaxz = bmaxy + FPS_MAX_BUCKETS;
     float *bestx = bmaxz + FPS_MAX_BUCKETS, *besty = bestx + FPS_MAX_BUCKETS, *bestz = besty + FPS_MAX_BUCKETS;
     int *worklist = reinterpret_cast<int *>(bestz + FPS_MAX_BUCKETS);  // [MAXB]
-    __shared__ unsigned long long wred[NW];
-    __shared__ float wcoord[NW][3];
+    __shared__ unsigned long long skey[FPS_MAX_SUPERS];
+    __shared__ float sbox[6][FPS_MAX_SUPERS];
+    __shared__ float sbest[3][FPS_MAX_SUPERS];
     __shared__ int wl_count;
 
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
     const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
     if (end_n <= start_n) {
-        for (int j = start_m + tid; j < end_m; j += FPS_BS) idx[j] = start_n;
+        for (int j = start_m + tid; j < end_m; j += NT) idx[j] = start_n;
         return;
     }
     const int n = end_n - start_n;
     const int nb = (n + BSZ - 1) / BSZ;
+    const int ns = (nb + FPS_SUPER - 1) / FPS_SUPER;
 
     // samples inherited from the previous call on this state
     int done = 0;
     if (prev_idx) {
         const int ps = bid == 0 ? 0 : prev_offset[bid - 1], pe = prev_offset[bid];
         done = min(pe - ps, end_m - start_m);
-        for (int t = tid; t < done; t += FPS_BS) idx[start_m + t] = prev_idx[ps + t];
+        for (int t = tid; t < done; t += NT) idx[start_m + t] = prev_idx[ps + t];
     }
     if (start_m + done >= end_m) return;
 
     // bucket boxes and cached keys from the current min-dist field (1e10 everywhere on a fresh start,
     // so the first step touches every bucket)
-    for (int bk = wave; bk < nb; bk += NW) {
+    for (int bk = wave; bk < nb; bk += FPS_NW) {
         const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
         float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
         unsigned long long best = 0ull;
@@ -201,13 +236,13 @@ __global__ __launch_bounds__(FPS_BS) void fps_bucket_kernel(int Bref, int log2B,
             mnx = fminf(mnx, __shfl_xor(mnx, st, 64)); mny = fminf(mny, __shfl_xor(mny, st, 64)); mnz = fminf(mnz, __shfl_xor(mnz, st, 64));
             mxx = fmaxf(mxx, __shfl_xor(mxx, st, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, st, 64)); mxz = fmaxf(mxz, __shfl_xor(mxz, st, 64));
         }
-        const unsigned long long wm = wmax64(best);
+        const KeyMax km = wave_key_max(best);
         if (lane == 0) {
             bminx[bk] = mnx; bminy[bk] = mny; bminz[bk] = mnz;
             bmaxx[bk] = mxx; bmaxy[bk] = mxy; bmaxz[bk] = mxz;
         }
-        if (best == wm && best != 0ull) {
-            bkey[bk] = wm;
+        if (lane == km.lane) {
+            bkey[bk] = km.key;
             bestx[bk] = bx; besty[bk] = by; bestz[bk] = bz;
         }
     }
@@ -215,65 +250,142 @@ __global__ __launch_bounds__(FPS_BS) void fps_bucket_kernel(int Bref, int log2B,
         wl_count = 0;
         if (done == 0) idx[start_m] = start_n;
     }
-    __syncthreads();  // also orders the idx[] copy above before the read below
+    __syncthreads();  // bucket records complete; also orders the idx[] copy above before the read below
+    // super-bucket boxes and keys
+    auto refresh_super = [&](int sb) {  // whole wave; lanes 0..31 <-> the super's buckets
+        const int bk = sb * FPS_SUPER + lane;
+        const bool ok = lane < FPS_SUPER && bk < nb;
+        const KeyMax km = wave_key_max(ok ? bkey[bk] : 0ull);
+        if (lane == km.lane) {
+            skey[sb] = km.key;
+            sbest[0][sb] = bestx[bk]; sbest[1][sb] = besty[bk]; sbest[2][sb] = bestz[bk];
+        }
+    };
+    for (int sb = wave; sb < ns; sb += FPS_NW) {
+        const int bk = sb * FPS_SUPER + lane;
+        const bool ok = lane < FPS_SUPER && bk < nb;
+        float v[6] = {ok ? bminx[bk] : INFINITY, ok ? bminy[bk] : INFINITY, ok ? bminz[bk] : INFINITY,
+                      ok ? bmaxx[bk] : -INFINITY, ok ? bmaxy[bk] : -INFINITY, ok ? bmaxz[bk] : -INFINITY};
+        for (int st = 1; st < 64; st <<= 1)
+            for (int a = 0; a < 6; a++) {
+                const float o = __shfl_xor(v[a], st, 64);
+                v[a] = a < 3 ? fminf(v[a], o) : fmaxf(v[a], o);
+            }
+        if (lane < 6) sbox[lane][sb] = v[lane];
+        refresh_super(sb);
+    }
+    __syncthreads();
     const int first = done == 0 ? start_n : idx[start_m + done - 1];
     float x1 = xyz[(size_t)first * 3 + 0], y1 = xyz[(size_t)first * 3 + 1], z1 = xyz[(size_t)first * 3 + 2];
 
     for (int j = start_m + max(done, 1); j < end_m; j++) {
-        // (a) which buckets can change?
-        for (int bk = tid; bk < nb; bk += FPS_BS) {
-            const float dx = fmaxf(fmaxf(bminx[bk] - x1, x1 - bmaxx[bk]), 0.f);
-            const float dy = fmaxf(fmaxf(bminy[bk] - y1, y1 - bmaxy[bk]), 0.f);
-            const float dz = fmaxf(fmaxf(bminz[bk] - z1, z1 - bmaxz[bk]), 0.f);
-            const float lb = sqd(dx, dy, dz);
-            const float bmaxd = __uint_as_float((unsigned)(bkey[bk] >> 32));
-            if (lb < bmaxd) worklist[atomicAdd(&wl_count, 1)] = bk;
+        // S1: touched supers (same result in every wave)
+        bool st_touched = false;
+        if (lane < ns) {
+            const float dx = fmaxf(fmaxf(sbox[0][lane] - x1, x1 - sbox[3][lane]), 0.f);
+            const float dy = fmaxf(fmaxf(sbox[1][lane] - y1, y1 - sbox[4][lane]), 0.f);
+            const float dz = fmaxf(fmaxf(sbox[2][lane] - z1, z1 - sbox[5][lane]), 0.f);
+            st_touched = sqd(dx, dy, dz) < __uint_as_float((unsigned)(skey[lane] >> 32));
+        }
+        const unsigned long long smask = __ballot(st_touched);
+        // S2: buckets of the supers this wave owns in this step
+        {
+            unsigned long long rest = smask;
+            int ord = 0;
+            while (rest) {
+                const int sb = __ffsll(rest) - 1;
+                rest &= rest - 1;
+                if ((ord++ & (FPS_NW - 1)) != wave) continue;
+                const int bk = sb * FPS_SUPER + lane;
+                bool hit = false;
+                if (lane < FPS_SUPER && bk < nb) {
+                    const float dx = fmaxf(fmaxf(bminx[bk] - x1, x1 - bmaxx[bk]), 0.f);
+                    const float dy = fmaxf(fmaxf(bminy[bk] - y1, y1 - bmaxy[bk]), 0.f);
+                    const float dz = fmaxf(fmaxf(bminz[bk] - z1, z1 - bmaxz[bk]), 0.f);
+                    hit = sqd(dx, dy, dz) < __uint_as_float((unsigned)(bkey[bk] >> 32));
+                }
+                const unsigned long long hm = __ballot(hit);
+                if (hm) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&wl_count, __popcll(hm));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (hit) worklist[base + __popcll(hm & ((1ull << lane) - 1))] = bk;
+                }
+            }
         }
         __syncthreads();
         const int cnt = wl_count;
-        // (b) update touched buckets, one wave each
-        for (int w = wave; w < cnt; w += NW) {
-            const int bk = worklist[w];
-            const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
-            unsigned long long best = 0ull;
-            float bx = 0.f, by = 0.f, bz = 0.f;
-            for (int pos = p0 + lane; pos < p1; pos += 64) {
-                const float4 p = pts[pos];
-                const unsigned rk = rank[pos];
-                const float d = sqd(p.x - x1, p.y - y1, p.z - z1);
-                const float d2 = fminf(d, p.w);
-                if (d2 != p.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | rk;
-                if (key > best) { best = key; bx = p.x; by = p.y; bz = p.z; }
+        // S3: update touched buckets; three buckets per wave in flight when a bucket is one wave wide
+        if (BSZ == 64) {
+            for (int w0 = wave * 3; w0 < cnt; w0 += FPS_NW * 3) {
+                int bk[3];
+                float4 p[3];
+                unsigned rk[3];
+                bool ok[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    bk[u] = w0 + u < cnt ? worklist[w0 + u] : -1;
+                    const int pos = start_n + bk[u] * 64 + lane;
+                    ok[u] = bk[u] >= 0 && pos < end_n;
+                    if (ok[u]) { p[u] = pts[pos]; rk[u] = rank[pos]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    if (bk[u] < 0) continue;  // wave-uniform
+                    unsigned long long key = 0ull;
+                    if (ok[u]) {
+                        const float d = sqd(p[u].x - x1, p[u].y - y1, p[u].z - z1);
+                        const float d2 = fminf(d, p[u].w);
+                        if (d2 != p[u].w) reinterpret_cast<float *>(pts + start_n + bk[u] * 64 + lane)[3] = d2;
+                        key = ((unsigned long long)__float_as_uint(d2) << 32) | rk[u];
+                    }
+                    const KeyMax km = wave_key_max(key);
+                    if (lane == km.lane) {
+                        bkey[bk[u]] = km.key;
+                        bestx[bk[u]] = p[u].x; besty[bk[u]] = p[u].y; bestz[bk[u]] = p[u].z;
+                    }
+                }
             }
-            const unsigned long long wm = wmax64(best);
-            if (best == wm && best != 0ull) {  // keys are unique: exactly one lane
-                bkey[bk] = wm;
-                bestx[bk] = bx; besty[bk] = by; bestz[bk] = bz;
+        } else {
+            for (int w = wave; w < cnt; w += FPS_NW) {
+                const int bk = worklist[w];
+                const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
+                unsigned long long best = 0ull;
+                float bx = 0.f, by = 0.f, bz = 0.f;
+                for (int pos = p0 + lane; pos < p1; pos += 64) {
+                    const float4 p = pts[pos];
+                    const unsigned rk = rank[pos];
+                    const float d = sqd(p.x - x1, p.y - y1, p.z - z1);
+                    const float d2 = fminf(d, p.w);
+                    if (d2 != p.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | rk;
+                    if (key > best) { best = key; bx = p.x; by = p.y; bz = p.z; }
+                }
+                const KeyMax km = wave_key_max(best);
+                if (lane == km.lane) {
+                    bkey[bk] = km.key;
+                    bestx[bk] = bx; besty[bk] = by; bestz[bk] = bz;
+                }
             }
         }
         __syncthreads();
-        // (c) arg-max over bucket keys
-        unsigned long long my = 0ull;
-        int mybk = 0;
-        for (int bk = tid; bk < nb; bk += FPS_BS) {
-            const unsigned long long kk = bkey[bk];
-            if (kk > my) { my = kk; mybk = bk; }
+        // S4: keys of the touched supers (same ownership as S2)
+        {
+            unsigned long long rest = smask;
+            int ord = 0;
+            while (rest) {
+                const int sb = __ffsll(rest) - 1;
+                rest &= rest - 1;
+                if ((ord++ & (FPS_NW - 1)) != wave) continue;
+                refresh_super(sb);
+            }
+            if (tid == 0) wl_count = 0;
         }
-        const unsigned long long wm = wmax64(my);
-        if (my == wm && my != 0ull) {
-            wred[wave] = wm;
-            wcoord[wave][0] = bestx[mybk]; wcoord[wave][1] = besty[mybk]; wcoord[wave][2] = bestz[mybk];
-        } else if (wm == 0ull && lane == 0) {
-            wred[wave] = 0ull;
-        }
-        if (tid == 0) wl_count = 0;
         __syncthreads();
-        unsigned long long v = lane < NW ? wred[lane] : 0ull;
-        const unsigned long long vm = wmax64(v);
-        const int src = __ffsll((unsigned long long)__ballot(v == vm && lane < NW)) - 1;
-        x1 = wcoord[src][0]; y1 = wcoord[src][1]; z1 = wcoord[src][2];
-        if (tid == 0) idx[j] = start_n + rel_of(vm, Bref, log2B);
+        // S5: arg-max over super keys (every wave computes the same winner)
+        const KeyMax km = wave_key_max(lane < ns ? skey[lane] : 0ull);
+        x1 = sbest[0][km.lane]; y1 = sbest[1][km.lane]; z1 = sbest[2][km.lane];
+        if (tid == 0) idx[j] = start_n + rel_of(km.key, Bref, log2B);
     }
 }
 
@@ -333,7 +445,7 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);
     const size_t lds = (size_t)FPS_MAX_BUCKETS * (8 + 9 * 4 + 4);
     allow_big_lds(fps_bucket_kernel, lds);
-    hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FPS_BS), lds, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
+    hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FPS_NW * 64), lds, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
                        rs.prev_idx, rs.prev_offset, idx);
     return true;
 }

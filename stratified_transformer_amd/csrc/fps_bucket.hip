@@ -144,19 +144,18 @@ __global__ void fps_gather_kernel(int N, int b, int Bref, int log2B, const float
 }
 
 // ---- sampling --------------------------------------------------------------------------------
-// Two-level hierarchy: buckets of BSZ points, super-buckets of 32 consecutive buckets (<= 64 supers, one
-// per lane).  Four waves (one per SIMD, so no wave shares a SIMD's issue slots); per step:
-//   S1  every wave (redundantly, no barrier): lane s tests super box s          -> 64-bit touched mask
-//   S2  wave w takes the touched supers with ordinal = w mod 4, tests their 32 buckets, appends the
-//       touched buckets to an LDS work list                                      -> barrier
-//   S3  waves update touched buckets, three per wave in flight (loads batched)   -> barrier
-//   S4  waves recompute the key of the supers they own in this step              -> barrier
-//   S5  every wave (redundantly): arg-max over the <= 64 super keys, winner coordinates from LDS
+// Static ownership, one barrier per step.  Bucket b belongs to wave b % NW, and inside that wave to one
+// lane, which keeps the bucket's box, cached key and arg-max coordinates IN REGISTERS (NBL buckets per
+// lane).  A step, per wave, with no synchronisation:
+//     test own buckets against the new sample (registers only)
+//     update the touched ones: 64 lanes <-> 64 points, up to four buckets' loads in flight; only the owning
+//       wave ever loads or stores a bucket's points, so program order alone keeps the min-dist field coherent
+//       and the step barrier does not have to wait for the stores to be acknowledged
+//     reduce the wave's best key -> LDS slot (ping-pong by step parity)
+// then ONE raw s_barrier (LDS only), and every wave reduces the NW slots to the winner and its coordinates.
 // prev_idx/prev_offset (optional): samples already computed on this workspace by an earlier call for the
 // same cloud (FPS is deterministic: a shorter request is a prefix of a longer one) — copied, then resumed.
-constexpr int FPS_SUPER = 32;                                 // buckets per super-bucket
-constexpr int FPS_MAX_SUPERS = FPS_MAX_BUCKETS / FPS_SUPER;   // 64
-constexpr int FPS_NW = 4;
+constexpr int FPS_NW = 8;
 
 struct KeyMax {
     unsigned long long key;  // wave maximum
@@ -180,23 +179,23 @@ __device__ __forceinline__ KeyMax wave_key_max(unsigned long long v) {
     return r;
 }
 
+__device__ __forceinline__ void lds_barrier() {
+    // LDS traffic of this wave retired, then the workgroup barrier; global stores stay in flight
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NBL>
 __global__ __launch_bounds__(FPS_NW * 64) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
                                                                  const int *__restrict__ offset, const int *__restrict__ new_offset,
                                                                  float4 *__restrict__ pts, const unsigned *__restrict__ rank,
                                                                  const int *__restrict__ prev_idx, const int *__restrict__ prev_offset,
                                                                  int *__restrict__ idx) {
     constexpr int NT = FPS_NW * 64;
-    extern __shared__ unsigned long long smem64[];
-    unsigned long long *bkey = smem64;                                  // [MAXB]
-    float *bminx = reinterpret_cast<float *>(bkey + FPS_MAX_BUCKETS);  // 6 x [MAXB] box, 3 x [MAXB] arg-max coords
-    float *bminy = bminx + FPS_MAX_BUCKETS, *bminz = bminy + FPS_MAX_BUCKETS;
-    float *bmaxx = bminz + FPS_MAX_BUCKETS, *bmaxy = bmaxx + FPS_MAX_BUCKETS, *bmaxz = bmaxy + FPS_MAX_BUCKETS;
-    float *bestx = bmaxz + FPS_MAX_BUCKETS, *besty = bestx + FPS_MAX_BUCKETS, *bestz = besty + FPS_MAX_BUCKETS;
-    int *worklist = reinterpret_cast<int *>(bestz + FPS_MAX_BUCKETS);  // [MAXB]
-    __shared__ unsigned long long skey[FPS_MAX_SUPERS];
-    __shared__ float sbox[6][FPS_MAX_SUPERS];
-    __shared__ float sbest[3][FPS_MAX_SUPERS];
-    __shared__ int wl_count;
+    __shared__ unsigned long long wkey[2][FPS_NW];
+    __shared__ float wbest[2][FPS_NW][4];
 
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
@@ -207,7 +206,6 @@ __global__ __launch_bounds__(FPS_NW * 64) void fps_bucket_kernel(int Bref, int l
     }
     const int n = end_n - start_n;
     const int nb = (n + BSZ - 1) / BSZ;
-    const int ns = (nb + FPS_SUPER - 1) / FPS_SUPER;
 
     // samples inherited from the previous call on this state
     int done = 0;
@@ -218,174 +216,126 @@ __global__ __launch_bounds__(FPS_NW * 64) void fps_bucket_kernel(int Bref, int l
     }
     if (start_m + done >= end_m) return;
 
-    // bucket boxes and cached keys from the current min-dist field (1e10 everywhere on a fresh start,
-    // so the first step touches every bucket)
-    for (int bk = wave; bk < nb; bk += FPS_NW) {
-        const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
-        float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
-        unsigned long long best = 0ull;
-        float bx = 0.f, by = 0.f, bz = 0.f;
-        for (int pos = p0 + lane; pos < p1; pos += 64) {
-            const float4 p = pts[pos];
-            mnx = fminf(mnx, p.x); mny = fminf(mny, p.y); mnz = fminf(mnz, p.z);
-            mxx = fmaxf(mxx, p.x); mxy = fmaxf(mxy, p.y); mxz = fmaxf(mxz, p.z);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(p.w) << 32) | rank[pos];
-            if (key > best) { best = key; bx = p.x; by = p.y; bz = p.z; }
-        }
-        for (int st = 1; st < 64; st <<= 1) {
-            mnx = fminf(mnx, __shfl_xor(mnx, st, 64)); mny = fminf(mny, __shfl_xor(mny, st, 64)); mnz = fminf(mnz, __shfl_xor(mnz, st, 64));
-            mxx = fmaxf(mxx, __shfl_xor(mxx, st, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, st, 64)); mxz = fmaxf(mxz, __shfl_xor(mxz, st, 64));
-        }
-        const KeyMax km = wave_key_max(best);
-        if (lane == 0) {
-            bminx[bk] = mnx; bminy[bk] = mny; bminz[bk] = mnz;
-            bmaxx[bk] = mxx; bmaxy[bk] = mxy; bmaxz[bk] = mxz;
-        }
-        if (lane == km.lane) {
-            bkey[bk] = km.key;
-            bestx[bk] = bx; besty[bk] = by; bestz[bk] = bz;
-        }
+    // owned buckets: slot s of lane l  <->  bucket (s*64 + l)*NW + wave
+    float mnx[NBL], mny[NBL], mnz[NBL], mxx[NBL], mxy[NBL], mxz[NBL], bx[NBL], by[NBL], bz[NBL];
+    unsigned long long key[NBL];
+#pragma unroll
+    for (int s = 0; s < NBL; s++) {
+        mnx[s] = mny[s] = mnz[s] = INFINITY;       // an absent bucket never passes the test below
+        mxx[s] = mxy[s] = mxz[s] = -INFINITY;
+        bx[s] = by[s] = bz[s] = 0.f;
+        key[s] = 0ull;
     }
-    if (tid == 0) {
-        wl_count = 0;
-        if (done == 0) idx[start_m] = start_n;
-    }
-    __syncthreads();  // bucket records complete; also orders the idx[] copy above before the read below
-    // super-bucket boxes and keys
-    auto refresh_super = [&](int sb) {  // whole wave; lanes 0..31 <-> the super's buckets
-        const int bk = sb * FPS_SUPER + lane;
-        const bool ok = lane < FPS_SUPER && bk < nb;
-        const KeyMax km = wave_key_max(ok ? bkey[bk] : 0ull);
-        if (lane == km.lane) {
-            skey[sb] = km.key;
-            sbest[0][sb] = bestx[bk]; sbest[1][sb] = besty[bk]; sbest[2][sb] = bestz[bk];
-        }
-    };
-    for (int sb = wave; sb < ns; sb += FPS_NW) {
-        const int bk = sb * FPS_SUPER + lane;
-        const bool ok = lane < FPS_SUPER && bk < nb;
-        float v[6] = {ok ? bminx[bk] : INFINITY, ok ? bminy[bk] : INFINITY, ok ? bminz[bk] : INFINITY,
-                      ok ? bmaxx[bk] : -INFINITY, ok ? bmaxy[bk] : -INFINITY, ok ? bmaxz[bk] : -INFINITY};
-        for (int st = 1; st < 64; st <<= 1)
-            for (int a = 0; a < 6; a++) {
-                const float o = __shfl_xor(v[a], st, 64);
-                v[a] = a < 3 ? fminf(v[a], o) : fmaxf(v[a], o);
+    // box + cached key of every owned bucket from the current min-dist field (1e10 everywhere on a fresh
+    // start, so the first step touches every bucket)
+#pragma unroll
+    for (int s = 0; s < NBL; s++) {
+        for (int l = 0; l < 64; l++) {
+            const int bk = (s * 64 + l) * FPS_NW + wave;
+            if (bk >= nb) break;
+            const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
+            float a0 = INFINITY, a1 = INFINITY, a2 = INFINITY, b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY;
+            unsigned long long best = 0ull;
+            float cx = 0.f, cy = 0.f, cz = 0.f;
+            for (int pos = p0 + lane; pos < p1; pos += 64) {
+                const float4 p = pts[pos];
+                a0 = fminf(a0, p.x); a1 = fminf(a1, p.y); a2 = fminf(a2, p.z);
+                b0 = fmaxf(b0, p.x); b1 = fmaxf(b1, p.y); b2 = fmaxf(b2, p.z);
+                const unsigned long long k = ((unsigned long long)__float_as_uint(p.w) << 32) | rank[pos];
+                if (k > best) { best = k; cx = p.x; cy = p.y; cz = p.z; }
             }
-        if (lane < 6) sbox[lane][sb] = v[lane];
-        refresh_super(sb);
+            for (int st = 1; st < 64; st <<= 1) {
+                a0 = fminf(a0, __shfl_xor(a0, st, 64)); a1 = fminf(a1, __shfl_xor(a1, st, 64)); a2 = fminf(a2, __shfl_xor(a2, st, 64));
+                b0 = fmaxf(b0, __shfl_xor(b0, st, 64)); b1 = fmaxf(b1, __shfl_xor(b1, st, 64)); b2 = fmaxf(b2, __shfl_xor(b2, st, 64));
+            }
+            const KeyMax km = wave_key_max(best);
+            const float wx = __shfl(cx, km.lane, 64), wy = __shfl(cy, km.lane, 64), wz = __shfl(cz, km.lane, 64);
+            if (lane == l) {
+                mnx[s] = a0; mny[s] = a1; mnz[s] = a2; mxx[s] = b0; mxy[s] = b1; mxz[s] = b2;
+                key[s] = km.key; bx[s] = wx; by[s] = wy; bz[s] = wz;
+            }
+        }
     }
-    __syncthreads();
+    if (tid == 0 && done == 0) idx[start_m] = start_n;
+    __syncthreads();  // orders the idx[] copy above before the read below
     const int first = done == 0 ? start_n : idx[start_m + done - 1];
     float x1 = xyz[(size_t)first * 3 + 0], y1 = xyz[(size_t)first * 3 + 1], z1 = xyz[(size_t)first * 3 + 2];
 
-    for (int j = start_m + max(done, 1); j < end_m; j++) {
-        // S1: touched supers (same result in every wave)
-        bool st_touched = false;
-        if (lane < ns) {
-            const float dx = fmaxf(fmaxf(sbox[0][lane] - x1, x1 - sbox[3][lane]), 0.f);
-            const float dy = fmaxf(fmaxf(sbox[1][lane] - y1, y1 - sbox[4][lane]), 0.f);
-            const float dz = fmaxf(fmaxf(sbox[2][lane] - z1, z1 - sbox[5][lane]), 0.f);
-            st_touched = sqd(dx, dy, dz) < __uint_as_float((unsigned)(skey[lane] >> 32));
-        }
-        const unsigned long long smask = __ballot(st_touched);
-        // S2: buckets of the supers this wave owns in this step
-        {
-            unsigned long long rest = smask;
-            int ord = 0;
-            while (rest) {
-                const int sb = __ffsll(rest) - 1;
-                rest &= rest - 1;
-                if ((ord++ & (FPS_NW - 1)) != wave) continue;
-                const int bk = sb * FPS_SUPER + lane;
-                bool hit = false;
-                if (lane < FPS_SUPER && bk < nb) {
-                    const float dx = fmaxf(fmaxf(bminx[bk] - x1, x1 - bmaxx[bk]), 0.f);
-                    const float dy = fmaxf(fmaxf(bminy[bk] - y1, y1 - bmaxy[bk]), 0.f);
-                    const float dz = fmaxf(fmaxf(bminz[bk] - z1, z1 - bmaxz[bk]), 0.f);
-                    hit = sqd(dx, dy, dz) < __uint_as_float((unsigned)(bkey[bk] >> 32));
-                }
-                const unsigned long long hm = __ballot(hit);
-                if (hm) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&wl_count, __popcll(hm));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (hit) worklist[base + __popcll(hm & ((1ull << lane) - 1))] = bk;
-                }
-            }
-        }
-        __syncthreads();
-        const int cnt = wl_count;
-        // S3: update touched buckets; three buckets per wave in flight when a bucket is one wave wide
-        if (BSZ == 64) {
-            for (int w0 = wave * 3; w0 < cnt; w0 += FPS_NW * 3) {
-                int bk[3];
-                float4 p[3];
-                unsigned rk[3];
-                bool ok[3];
+    int par = 0;
+    for (int j = start_m + max(done, 1); j < end_m; j++, par ^= 1) {
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    bk[u] = w0 + u < cnt ? worklist[w0 + u] : -1;
-                    const int pos = start_n + bk[u] * 64 + lane;
-                    ok[u] = bk[u] >= 0 && pos < end_n;
-                    if (ok[u]) { p[u] = pts[pos]; rk[u] = rank[pos]; }
-                }
+        for (int s = 0; s < NBL; s++) {
+            const float dx = fmaxf(fmaxf(mnx[s] - x1, x1 - mxx[s]), 0.f);
+            const float dy = fmaxf(fmaxf(mny[s] - y1, y1 - mxy[s]), 0.f);
+            const float dz = fmaxf(fmaxf(mnz[s] - z1, z1 - mxz[s]), 0.f);
+            const bool hit = sqd(dx, dy, dz) < __uint_as_float((unsigned)(key[s] >> 32));
+            unsigned long long hm = __ballot(hit);
+            while (hm) {
+                // up to four touched buckets of this slot: issue all their loads, then reduce one by one
+                int ln[4];
+                float4 p[4];
+                unsigned rk[4];
+                bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    if (bk[u] < 0) continue;  // wave-uniform
-                    unsigned long long key = 0ull;
-                    if (ok[u]) {
-                        const float d = sqd(p[u].x - x1, p[u].y - y1, p[u].z - z1);
-                        const float d2 = fminf(d, p[u].w);
-                        if (d2 != p[u].w) reinterpret_cast<float *>(pts + start_n + bk[u] * 64 + lane)[3] = d2;
-                        key = ((unsigned long long)__float_as_uint(d2) << 32) | rk[u];
-                    }
-                    const KeyMax km = wave_key_max(key);
-                    if (lane == km.lane) {
-                        bkey[bk[u]] = km.key;
-                        bestx[bk[u]] = p[u].x; besty[bk[u]] = p[u].y; bestz[bk[u]] = p[u].z;
+                for (int u = 0; u < 4; u++) {
+                    ln[u] = hm ? __ffsll(hm) - 1 : -1;
+                    if (hm) hm &= hm - 1;
+                }
+                if (BSZ == 64) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int pos = start_n + ((s * 64 + ln[u]) * FPS_NW + wave) * 64 + lane;
+                        ok[u] = ln[u] >= 0 && pos < end_n;
+                        if (ok[u]) { p[u] = pts[pos]; rk[u] = rank[pos]; }
                     }
                 }
-            }
-        } else {
-            for (int w = wave; w < cnt; w += FPS_NW) {
-                const int bk = worklist[w];
-                const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
-                unsigned long long best = 0ull;
-                float bx = 0.f, by = 0.f, bz = 0.f;
-                for (int pos = p0 + lane; pos < p1; pos += 64) {
-                    const float4 p = pts[pos];
-                    const unsigned rk = rank[pos];
-                    const float d = sqd(p.x - x1, p.y - y1, p.z - z1);
-                    const float d2 = fminf(d, p.w);
-                    if (d2 != p.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | rk;
-                    if (key > best) { best = key; bx = p.x; by = p.y; bz = p.z; }
-                }
-                const KeyMax km = wave_key_max(best);
-                if (lane == km.lane) {
-                    bkey[bk] = km.key;
-                    bestx[bk] = bx; besty[bk] = by; bestz[bk] = bz;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (ln[u] < 0) continue;  // wave-uniform
+                    unsigned long long best = 0ull;
+                    float cx = 0.f, cy = 0.f, cz = 0.f;
+                    if (BSZ == 64) {
+                        if (ok[u]) {
+                            const float d = sqd(p[u].x - x1, p[u].y - y1, p[u].z - z1);
+                            const float d2 = fminf(d, p[u].w);
+                            if (d2 != p[u].w)
+                                reinterpret_cast<float *>(pts + start_n + ((s * 64 + ln[u]) * FPS_NW + wave) * 64 + lane)[3] = d2;
+                            best = ((unsigned long long)__float_as_uint(d2) << 32) | rk[u];
+                            cx = p[u].x; cy = p[u].y; cz = p[u].z;
+                        }
+                    } else {
+                        const int bk = (s * 64 + ln[u]) * FPS_NW + wave;
+                        const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
+                        for (int pos = p0 + lane; pos < p1; pos += 64) {
+                            const float4 q = pts[pos];
+                            const float d = sqd(q.x - x1, q.y - y1, q.z - z1);
+                            const float d2 = fminf(d, q.w);
+                            if (d2 != q.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
+                            const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | rank[pos];
+                            if (k > best) { best = k; cx = q.x; cy = q.y; cz = q.z; }
+                        }
+                    }
+                    const KeyMax km = wave_key_max(best);
+                    const float wx = __shfl(cx, km.lane, 64), wy = __shfl(cy, km.lane, 64), wz = __shfl(cz, km.lane, 64);
+                    if (lane == ln[u]) { key[s] = km.key; bx[s] = wx; by[s] = wy; bz[s] = wz; }
                 }
             }
         }
-        __syncthreads();
-        // S4: keys of the touched supers (same ownership as S2)
-        {
-            unsigned long long rest = smask;
-            int ord = 0;
-            while (rest) {
-                const int sb = __ffsll(rest) - 1;
-                rest &= rest - 1;
-                if ((ord++ & (FPS_NW - 1)) != wave) continue;
-                refresh_super(sb);
-            }
-            if (tid == 0) wl_count = 0;
+        // the wave's best bucket
+        unsigned long long mk = key[0];
+        float mx_ = bx[0], my_ = by[0], mz_ = bz[0];
+#pragma unroll
+        for (int s = 1; s < NBL; s++)
+            if (key[s] > mk) { mk = key[s]; mx_ = bx[s]; my_ = by[s]; mz_ = bz[s]; }
+        const KeyMax wm = wave_key_max(mk);
+        if (lane == wm.lane) {
+            wkey[par][wave] = wm.key;
+            wbest[par][wave][0] = mx_; wbest[par][wave][1] = my_; wbest[par][wave][2] = mz_;
         }
-        __syncthreads();
-        // S5: arg-max over super keys (every wave computes the same winner)
-        const KeyMax km = wave_key_max(lane < ns ? skey[lane] : 0ull);
-        x1 = sbest[0][km.lane]; y1 = sbest[1][km.lane]; z1 = sbest[2][km.lane];
-        if (tid == 0) idx[j] = start_n + rel_of(km.key, Bref, log2B);
+        lds_barrier();
+        const KeyMax gm = wave_key_max(lane < FPS_NW ? wkey[par][lane] : 0ull);
+        x1 = wbest[par][gm.lane][0]; y1 = wbest[par][gm.lane][1]; z1 = wbest[par][gm.lane][2];
+        if (tid == 0) idx[j] = start_n + rel_of(gm.key, Bref, log2B);
     }
 }
 
@@ -443,10 +393,17 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
         hipLaunchKernelGGL(fps_gather_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, b, Bref, log2B, xyz, offset, sorig, pts, rank);
     }
     const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);
-    const size_t lds = (size_t)FPS_MAX_BUCKETS * (8 + 9 * 4 + 4);
-    allow_big_lds(fps_bucket_kernel, lds);
-    hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FPS_NW * 64), lds, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
-                       rs.prev_idx, rs.prev_offset, idx);
+    const int nbuckets = div_up(n, BSZ);
+    const int per_lane = div_up(nbuckets, FPS_NW * 64);
+    if (per_lane <= 1)
+        hipLaunchKernelGGL(fps_bucket_kernel<1>, dim3(b), dim3(FPS_NW * 64), 0, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
+                           rs.prev_idx, rs.prev_offset, idx);
+    else if (per_lane <= 2)
+        hipLaunchKernelGGL(fps_bucket_kernel<2>, dim3(b), dim3(FPS_NW * 64), 0, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
+                           rs.prev_idx, rs.prev_offset, idx);
+    else
+        hipLaunchKernelGGL(fps_bucket_kernel<4>, dim3(b), dim3(FPS_NW * 64), 0, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
+                           rs.prev_idx, rs.prev_offset, idx);
     return true;
 }
 

@@ -154,6 +154,11 @@ void pointops2_set_table_rows(int L);
  * signature only carries the largest batch element).  Otherwise the single-workgroup scan runs. */
 void pointops2_set_workspace(void *device_ptr, size_t bytes);
 void pointops2_set_point_count(int N);
+/* Grid-accelerated exact kNN (same idx/dist2 as the reference's full scan, ties replayed literally):
+ * taken by knnquery_cuda_launcher when a workspace of pointops2_knn_workspace_bytes(n, m, b) bytes is
+ * lent and the candidate count n (pointops2_set_point_count) and batch count b are announced. */
+void pointops2_set_batch_count(int b);
+size_t pointops2_knn_workspace_bytes(int n, int m, int b);
 size_t pointops2_fps_workspace_bytes(int b, int N);
 /* FPS is deterministic, so a request for fewer samples of the same cloud is a prefix of a longer one
  * (the model asks for n/8+1 and then n/4+1 samples of the same points, stratified_transformer.py:289,103).

@@ -22,6 +22,7 @@ SIGNATURES = {
     "pointops2_set_table_rows": [I],
     "pointops2_set_workspace": [P, Z],
     "pointops2_set_point_count": [I],
+    "pointops2_set_batch_count": [I],
     "pointops2_set_fps_resume": [P, P],
     "pointops2_set_csc": [P, P, P],
     "pointops2_csc_build": [I, I, P, P, P, P, P, P, Z],
@@ -60,6 +61,7 @@ RESULTS = {
     "pointops2_abi_version": ([], I),
     "pointops2_csc_workspace_bytes": ([I, I], Z),
     "pointops2_fps_workspace_bytes": ([I, I], Z),
+    "pointops2_knn_workspace_bytes": ([I, I, I], Z),
 }
 
 

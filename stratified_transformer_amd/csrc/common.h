@@ -15,13 +15,27 @@ struct LaunchState {
     const int *csc_offsets = nullptr;
     const int *csc_pair = nullptr;
     const int *csc_query = nullptr;
-    int total_points = 0;  // pointops2_set_point_count: N of the next furthestsampling call (0 = unknown)
+    int total_points = 0;  // pointops2_set_point_count: N of the next furthestsampling / knnquery call (0 = unknown)
+    int batch_count = 0;   // pointops2_set_batch_count: b of the next knnquery call (0 = unknown)
 };
+
+// scratch memory lent by the caller (pointops2_set_workspace), thread-local
+struct Workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+Workspace &workspace();
 LaunchState &state();
 
 // fps_bucket.hip: returns false when the bucketed path does not apply (no workspace / unknown N)
 bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset,
                        int N_total, int *idx);
+
+// fps_bucket.hip: per-batch-element bounding boxes [b][6] (min xyz, max xyz)
+void launch_bbox(int b, const float *xyz, const int *offset, float *bbox, hipStream_t st);
+// knn_grid.hip: returns false when the grid path does not apply (no workspace / unknown n, b / tiny problem)
+bool knn_grid_launch(int m, int k, int n, int b, const float *xyz, const float *new_xyz, const int *offset,
+                     const int *new_offset, int *idx, float *dist2);
 
 inline void set_error(const char *msg) { state().error = msg; }
 

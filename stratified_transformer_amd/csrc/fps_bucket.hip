@@ -25,13 +25,11 @@
 // One workgroup per batch element (as the reference): no cross-workgroup synchronisation at all.
 #include "common.h"
 #include <hipcub/hipcub.hpp>
+#include <cstdio>
+#include <cstdlib>
 
 namespace p2 {
 
-struct Workspace {
-    void *ptr = nullptr;
-    size_t bytes = 0;
-};
 Workspace &workspace() {
     static thread_local Workspace w;
     return w;
@@ -103,6 +101,10 @@ __global__ __launch_bounds__(256) void fps_bbox_kernel(const float *__restrict__
     else if (tid < 6) bbox[bid * 6 + tid] = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
 }
 
+void launch_bbox(int b, const float *xyz, const int *offset, float *bbox, hipStream_t st) {
+    hipLaunchKernelGGL(fps_bbox_kernel, dim3(b), dim3(256), 0, st, xyz, offset, bbox);
+}
+
 __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
     v &= 0x3ff;
     v = (v | (v << 16)) & 0x030000ff;
@@ -155,7 +157,6 @@ __global__ void fps_gather_kernel(int N, int b, int Bref, int log2B, const float
 // then ONE raw s_barrier (LDS only), and every wave reduces the NW slots to the winner and its coordinates.
 // prev_idx/prev_offset (optional): samples already computed on this workspace by an earlier call for the
 // same cloud (FPS is deterministic: a shorter request is a prefix of a longer one) — copied, then resumed.
-constexpr int FPS_NW = 8;
 
 struct KeyMax {
     unsigned long long key;  // wave maximum
@@ -187,15 +188,33 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NBL>
-__global__ __launch_bounds__(FPS_NW * 64) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
-                                                                 const int *__restrict__ offset, const int *__restrict__ new_offset,
-                                                                 float4 *__restrict__ pts, const unsigned *__restrict__ rank,
-                                                                 const int *__restrict__ prev_idx, const int *__restrict__ prev_offset,
-                                                                 int *__restrict__ idx) {
-    constexpr int NT = FPS_NW * 64;
-    __shared__ unsigned long long wkey[2][FPS_NW];
-    __shared__ float wbest[2][FPS_NW][4];
+__device__ __forceinline__ float rl(float v, int lane) {  // value of a wave-uniform lane, no LDS round trip
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// branch-free variant (two DPP passes), so that several independent reductions can be interleaved
+__device__ __forceinline__ KeyMax wave_key_max_bf(unsigned long long v) {
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mh = wave_max_u32(hi);
+    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    KeyMax r;
+    r.key = ((unsigned long long)mh << 32) | ml;
+    r.lane = __ffsll((unsigned long long)__ballot(hi == mh && lo == ml)) - 1;
+    return r;
+}
+
+// STAMP: diagnostic build only (P2_FPS_STAMPS=1): per-wave cycle sums of the step phases -> dbg
+template <int NBL, int NW, bool STAMP = false>
+__global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
+                                                             const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                             float4 *__restrict__ pts, const unsigned *__restrict__ rank,
+                                                             const int *__restrict__ prev_idx, const int *__restrict__ prev_offset,
+                                                             int *__restrict__ idx, unsigned long long *__restrict__ dbg = nullptr) {
+    constexpr int NT = NW * 64;
+    unsigned long long c_test = 0, c_red = 0, c_bar = 0, c_fin = 0, n_upd = 0, t_a = 0, t_b = 0;
+    unsigned long long rt0 = 0, ct0 = 0;
+    if (STAMP) { rt0 = __builtin_amdgcn_s_memrealtime(); ct0 = __builtin_amdgcn_s_memtime(); }
+    __shared__ unsigned long long wkey[2][NW];
+    __shared__ float4 wbest[2][NW];
 
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(FPS_NW * 64) void fps_bucket_kernel(int Bref, int l
 #pragma unroll
     for (int s = 0; s < NBL; s++) {
         for (int l = 0; l < 64; l++) {
-            const int bk = (s * 64 + l) * FPS_NW + wave;
+            const int bk = (s * 64 + l) * NW + wave;
             if (bk >= nb) break;
             const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
             float a0 = INFINITY, a1 = INFINITY, a2 = INFINITY, b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY;
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(FPS_NW * 64) void fps_bucket_kernel(int Bref, int l
                 b0 = fmaxf(b0, __shfl_xor(b0, st, 64)); b1 = fmaxf(b1, __shfl_xor(b1, st, 64)); b2 = fmaxf(b2, __shfl_xor(b2, st, 64));
             }
             const KeyMax km = wave_key_max(best);
-            const float wx = __shfl(cx, km.lane, 64), wy = __shfl(cy, km.lane, 64), wz = __shfl(cz, km.lane, 64);
+            const float wx = rl(cx, km.lane), wy = rl(cy, km.lane), wz = rl(cz, km.lane);
             if (lane == l) {
                 mnx[s] = a0; mny[s] = a1; mnz[s] = a2; mxx[s] = b0; mxy[s] = b1; mxz[s] = b2;
                 key[s] = km.key; bx[s] = wx; by[s] = wy; bz[s] = wz;
@@ -261,81 +280,126 @@ __global__ __launch_bounds__(FPS_NW * 64) void fps_bucket_kernel(int Bref, int l
     const int first = done == 0 ? start_n : idx[start_m + done - 1];
     float x1 = xyz[(size_t)first * 3 + 0], y1 = xyz[(size_t)first * 3 + 1], z1 = xyz[(size_t)first * 3 + 2];
 
+    // the wave's best bucket, kept wave-uniform between steps; recomputed only after an update
+    unsigned long long wk = 0ull;
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    bool dirty = true;
+
     int par = 0;
     for (int j = start_m + max(done, 1); j < end_m; j++, par ^= 1) {
+        if (STAMP) t_a = __builtin_amdgcn_s_memtime();
+        unsigned long long hm[NBL];
+        unsigned long long any = 0ull;
 #pragma unroll
         for (int s = 0; s < NBL; s++) {
             const float dx = fmaxf(fmaxf(mnx[s] - x1, x1 - mxx[s]), 0.f);
             const float dy = fmaxf(fmaxf(mny[s] - y1, y1 - mxy[s]), 0.f);
             const float dz = fmaxf(fmaxf(mnz[s] - z1, z1 - mxz[s]), 0.f);
-            const bool hit = sqd(dx, dy, dz) < __uint_as_float((unsigned)(key[s] >> 32));
-            unsigned long long hm = __ballot(hit);
-            while (hm) {
-                // up to four touched buckets of this slot: issue all their loads, then reduce one by one
-                int ln[4];
+            hm[s] = __ballot(sqd(dx, dy, dz) < __uint_as_float((unsigned)(key[s] >> 32)));
+            any |= hm[s];
+        }
+        while (any) {
+            dirty = true;
+            // next (up to) four touched buckets across all slots: code = slot*64 + owner lane, -1 = none
+            int code[4];
+            any = 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                code[u] = -1;
+#pragma unroll
+                for (int s = 0; s < NBL; s++)
+                    if (code[u] < 0 && hm[s]) {
+                        code[u] = s * 64 + __ffsll(hm[s]) - 1;
+                        hm[s] &= hm[s] - 1;
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < NBL; s++) any |= hm[s];
+            if (STAMP) n_upd += (code[0] >= 0) + (code[1] >= 0) + (code[2] >= 0) + (code[3] >= 0);
+            if (BSZ == 64) {
+                // all loads first (kept in flight together), then one reduction per touched bucket
                 float4 p[4];
                 unsigned rk[4];
                 bool ok[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    ln[u] = hm ? __ffsll(hm) - 1 : -1;
-                    if (hm) hm &= hm - 1;
-                }
-                if (BSZ == 64) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int pos = start_n + ((s * 64 + ln[u]) * FPS_NW + wave) * 64 + lane;
-                        ok[u] = ln[u] >= 0 && pos < end_n;
-                        if (ok[u]) { p[u] = pts[pos]; rk[u] = rank[pos]; }
-                    }
+                    const int pos = start_n + (max(code[u], 0) * NW + wave) * 64 + lane;
+                    ok[u] = code[u] >= 0 && pos < end_n;
+                    p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    rk[u] = 0u;
+                    if (ok[u]) { p[u] = pts[pos]; rk[u] = rank[pos]; }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    if (ln[u] < 0) continue;  // wave-uniform
+                    if (code[u] < 0) continue;  // wave-uniform: absent entries cost nothing
+                    unsigned long long k = 0ull;
+                    if (ok[u]) {
+                        const float d = sqd(p[u].x - x1, p[u].y - y1, p[u].z - z1);
+                        const float d2 = fminf(d, p[u].w);
+                        if (d2 != p[u].w) reinterpret_cast<float *>(pts + start_n + (code[u] * NW + wave) * 64 + lane)[3] = d2;
+                        k = ((unsigned long long)__float_as_uint(d2) << 32) | rk[u];
+                    }
+                    const KeyMax km = wave_key_max(k);
+                    const float cx = rl(p[u].x, km.lane), cy = rl(p[u].y, km.lane), cz = rl(p[u].z, km.lane);
+#pragma unroll
+                    for (int s = 0; s < NBL; s++)
+                        if ((code[u] >> 6) == s && lane == (code[u] & 63)) { key[s] = km.key; bx[s] = cx; by[s] = cy; bz[s] = cz; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (code[u] < 0) continue;  // wave-uniform
+                    const int bk = code[u] * NW + wave;
+                    const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
                     unsigned long long best = 0ull;
                     float cx = 0.f, cy = 0.f, cz = 0.f;
-                    if (BSZ == 64) {
-                        if (ok[u]) {
-                            const float d = sqd(p[u].x - x1, p[u].y - y1, p[u].z - z1);
-                            const float d2 = fminf(d, p[u].w);
-                            if (d2 != p[u].w)
-                                reinterpret_cast<float *>(pts + start_n + ((s * 64 + ln[u]) * FPS_NW + wave) * 64 + lane)[3] = d2;
-                            best = ((unsigned long long)__float_as_uint(d2) << 32) | rk[u];
-                            cx = p[u].x; cy = p[u].y; cz = p[u].z;
-                        }
-                    } else {
-                        const int bk = (s * 64 + ln[u]) * FPS_NW + wave;
-                        const int p0 = start_n + bk * BSZ, p1 = min(p0 + BSZ, end_n);
-                        for (int pos = p0 + lane; pos < p1; pos += 64) {
-                            const float4 q = pts[pos];
-                            const float d = sqd(q.x - x1, q.y - y1, q.z - z1);
-                            const float d2 = fminf(d, q.w);
-                            if (d2 != q.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
-                            const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | rank[pos];
-                            if (k > best) { best = k; cx = q.x; cy = q.y; cz = q.z; }
-                        }
+                    for (int pos = p0 + lane; pos < p1; pos += 64) {
+                        const float4 q = pts[pos];
+                        const float d = sqd(q.x - x1, q.y - y1, q.z - z1);
+                        const float d2 = fminf(d, q.w);
+                        if (d2 != q.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | rank[pos];
+                        if (k > best) { best = k; cx = q.x; cy = q.y; cz = q.z; }
                     }
                     const KeyMax km = wave_key_max(best);
-                    const float wx = __shfl(cx, km.lane, 64), wy = __shfl(cy, km.lane, 64), wz = __shfl(cz, km.lane, 64);
-                    if (lane == ln[u]) { key[s] = km.key; bx[s] = wx; by[s] = wy; bz[s] = wz; }
+                    const float ux = rl(cx, km.lane), uy = rl(cy, km.lane), uz = rl(cz, km.lane);
+#pragma unroll
+                    for (int s = 0; s < NBL; s++)
+                        if ((code[u] >> 6) == s && lane == (code[u] & 63)) { key[s] = km.key; bx[s] = ux; by[s] = uy; bz[s] = uz; }
                 }
             }
         }
-        // the wave's best bucket
-        unsigned long long mk = key[0];
-        float mx_ = bx[0], my_ = by[0], mz_ = bz[0];
+        if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_test += t_b - t_a; t_a = t_b; }
+        if (dirty) {  // wave-uniform
+            unsigned long long mk = key[0];
+            float mx_ = bx[0], my_ = by[0], mz_ = bz[0];
 #pragma unroll
-        for (int s = 1; s < NBL; s++)
-            if (key[s] > mk) { mk = key[s]; mx_ = bx[s]; my_ = by[s]; mz_ = bz[s]; }
-        const KeyMax wm = wave_key_max(mk);
-        if (lane == wm.lane) {
-            wkey[par][wave] = wm.key;
-            wbest[par][wave][0] = mx_; wbest[par][wave][1] = my_; wbest[par][wave][2] = mz_;
+            for (int s = 1; s < NBL; s++)
+                if (key[s] > mk) { mk = key[s]; mx_ = bx[s]; my_ = by[s]; mz_ = bz[s]; }
+            const KeyMax wm = wave_key_max(mk);
+            wk = wm.key;
+            wx = rl(mx_, wm.lane); wy = rl(my_, wm.lane); wz = rl(mz_, wm.lane);
+            dirty = false;
         }
+        if (lane == 0) {
+            wkey[par][wave] = wk;
+            wbest[par][wave] = make_float4(wx, wy, wz, 0.f);
+        }
+        if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_red += t_b - t_a; t_a = t_b; }
         lds_barrier();
-        const KeyMax gm = wave_key_max(lane < FPS_NW ? wkey[par][lane] : 0ull);
-        x1 = wbest[par][gm.lane][0]; y1 = wbest[par][gm.lane][1]; z1 = wbest[par][gm.lane][2];
+        if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_bar += t_b - t_a; t_a = t_b; }
+        const int src = lane < NW ? lane : 0;
+        const unsigned long long gk = wkey[par][src];
+        const float4 gc = wbest[par][src];
+        const KeyMax gm = wave_key_max(lane < NW ? gk : 0ull);
+        x1 = rl(gc.x, gm.lane); y1 = rl(gc.y, gm.lane); z1 = rl(gc.z, gm.lane);
         if (tid == 0) idx[j] = start_n + rel_of(gm.key, Bref, log2B);
+        if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_fin += t_b - t_a; }
+    }
+    if (STAMP && dbg && lane == 0) {
+        unsigned long long *o = dbg + (blockIdx.x * NW + wave) * 8;
+        o[0] = c_test; o[1] = 0; o[2] = c_red; o[3] = c_bar; o[4] = c_fin; o[5] = n_upd;
+        o[6] = __builtin_amdgcn_s_memtime() - ct0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
 }
 
@@ -394,16 +458,34 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     }
     const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);
     const int nbuckets = div_up(n, BSZ);
-    const int per_lane = div_up(nbuckets, FPS_NW * 64);
-    if (per_lane <= 1)
-        hipLaunchKernelGGL(fps_bucket_kernel<1>, dim3(b), dim3(FPS_NW * 64), 0, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
-                           rs.prev_idx, rs.prev_offset, idx);
-    else if (per_lane <= 2)
-        hipLaunchKernelGGL(fps_bucket_kernel<2>, dim3(b), dim3(FPS_NW * 64), 0, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
-                           rs.prev_idx, rs.prev_offset, idx);
-    else
-        hipLaunchKernelGGL(fps_bucket_kernel<4>, dim3(b), dim3(FPS_NW * 64), 0, st, Bref, log2B, BSZ, xyz, offset, new_offset, pts, rank,
-                           rs.prev_idx, rs.prev_offset, idx);
+    static const int nw_env = getenv("P2_FPS_WAVES") ? atoi(getenv("P2_FPS_WAVES")) : 0;
+    const int NWsel = nw_env == 8 ? 8 : 16;
+    const int per_lane = div_up(nbuckets, NWsel * 64);
+#define P2_FPS_LAUNCH(NBL_, NW_, STAMP_, DBG_)                                                                              \
+    hipLaunchKernelGGL((fps_bucket_kernel<NBL_, NW_, STAMP_>), dim3(b), dim3(NW_ * 64), 0, st, Bref, log2B, BSZ, xyz, offset, \
+                       new_offset, pts, rank, rs.prev_idx, rs.prev_offset, idx, DBG_)
+    if (getenv("P2_FPS_STAMPS") && nbuckets > 1024) {  // diagnostic only: synchronous, prints phase shares to stderr
+        unsigned long long *dbg = nullptr, host[16 * 8];
+        (void)hipMalloc(&dbg, sizeof(host) * b);
+        if (NWsel == 8) P2_FPS_LAUNCH(4, 8, true, dbg); else P2_FPS_LAUNCH(2, 16, true, dbg);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+        (void)hipFree(dbg);
+        for (int w = 0; w < NWsel; w++)
+            fprintf(stderr, "[fps stamps] wave %2d: test+update %llu reduce %llu barrier %llu final %llu | updates %llu | cycles %llu realtime(100MHz) %llu -> %.0f MHz\n",
+                    w, host[w * 8 + 0], host[w * 8 + 2], host[w * 8 + 3], host[w * 8 + 4], host[w * 8 + 5], host[w * 8 + 6], host[w * 8 + 7],
+                    host[w * 8 + 7] ? 100.0 * host[w * 8 + 6] / host[w * 8 + 7] : 0.0);
+        return true;
+    }
+    if (NWsel == 8) {
+        if (per_lane <= 1) P2_FPS_LAUNCH(1, 8, false, nullptr);
+        else if (per_lane <= 2) P2_FPS_LAUNCH(2, 8, false, nullptr);
+        else P2_FPS_LAUNCH(4, 8, false, nullptr);
+    } else {
+        if (per_lane <= 1) P2_FPS_LAUNCH(1, 16, false, nullptr);
+        else P2_FPS_LAUNCH(2, 16, false, nullptr);
+    }
+#undef P2_FPS_LAUNCH
     return true;
 }
 

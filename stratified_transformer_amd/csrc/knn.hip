@@ -125,6 +125,14 @@ void knnquery_cuda_launcher(int m, int nsample, const float *xyz, const float *n
     if (m <= 0) return;
     if (nsample < 1 || nsample > 100) { set_error("knnquery: nsample must be in [1, 100]"); return; }
     hipStream_t st = state().stream;
+    const int n_total = state().total_points, nbatch = state().batch_count;
+    state().total_points = 0;
+    state().batch_count = 0;
+    // grid-accelerated exact kNN (knn_grid.hip) when the caller lent scratch memory and announced n and b
+    if (knn_grid_launch(m, nsample, n_total, nbatch, xyz, new_xyz, offset, new_offset, idx, dist2)) {
+        check_launch();
+        return;
+    }
     auto launch = [&](auto bs_tag) {
         constexpr int BS = decltype(bs_tag)::value;
         const size_t lds = KNN_TILE * sizeof(float4) + (size_t)nsample * BS * 8;

@@ -93,6 +93,7 @@ const char *pointops2_last_error(void) {
 int pointops2_abi_version(void) { return 1; }
 void pointops2_set_table_rows(int L) { state().table_rows = L; }
 void pointops2_set_point_count(int N) { state().total_points = N; }
+void pointops2_set_batch_count(int b) { state().batch_count = b; }
 void pointops2_set_csc(const int *csc_offsets, const int *csc_pair, const int *csc_query) {
     LaunchState &s = state();
     s.csc_offsets = csc_offsets;

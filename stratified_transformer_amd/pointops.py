@@ -176,7 +176,17 @@ class KNNQuery(Function):
         m = new_xyz.shape[0]
         idx = _zeros((m, nsample), xyz, torch.int32)
         dist2 = _zeros((m, nsample), xyz)
-        pointops_cuda.knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
+        # lend scratch memory for the grid-accelerated exact search (csrc/knn_grid.hip)
+        l = _lib.lib()
+        n, b = xyz.shape[0], offset.shape[0]
+        ws = torch.empty(int(l.pointops2_knn_workspace_bytes(n, m, b)), dtype=torch.uint8, device=xyz.device)
+        l.pointops2_set_workspace(ptr(ws), ws.numel())
+        l.pointops2_set_point_count(n)
+        l.pointops2_set_batch_count(b)
+        try:
+            pointops_cuda.knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
+        finally:
+            l.pointops2_set_workspace(None, 0)
         return idx, torch.sqrt(dist2)
 
 

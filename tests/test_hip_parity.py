@@ -356,3 +356,32 @@ def test_fps_prefix_reuse_and_resume(P):
     assert np.array_equal(d, ref.furthestsampling(xyz, np.array([3000, 7000], np.int32), np.array([800, 1000], np.int32)))
     P.clear_caches()
     assert np.array_equal(_np(P.furthestsampling(x, off, dev(np.array([751, 1752], np.int32)))), full)
+
+
+def test_knn_grid_path_ties_outliers_and_scan_agree(P):
+    """Sizes above the grid threshold (m*n >= 2^22): exact ties go through the replay list, queries far
+    outside the cloud walk the whole grid, and the lent-workspace path equals the plain scan."""
+    from stratified_transformer_amd import _lib, pointops2_cuda
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    g = g[np.random.default_rng(5).permutation(len(g))] * 0.25
+    rng = np.random.default_rng(6)
+    q = np.concatenate([g[:900], g[:500] + rng.normal(0, 0.01, (500, 3)).astype(np.float32),
+                        rng.uniform(-30, 30, (100, 3)).astype(np.float32)]).astype(np.float32)
+    for k in (16, 3):
+        for offset, new_offset in (([3072], [1500]), ([1000, 3072], [600, 1500])):
+            i_ref, d_ref = ref.knnquery(k, g, q, np.asarray(offset, np.int32), np.asarray(new_offset, np.int32))
+            i_got, d_got = _knn(P, k, g, q, offset, new_offset)
+            assert np.array_equal(i_got, i_ref), (k, offset)
+            assert np.array_equal(d_got, d_ref), (k, offset)
+    # plain scan (no workspace lent) on a random cloud == grid path == oracle
+    xyz = rng.random((8000, 3), dtype=np.float32)
+    nq = np.ascontiguousarray(xyz[:2000])
+    off, noff = dev(np.array([8000], np.int32)), dev(np.array([2000], np.int32))
+    idx = torch.zeros((2000, 16), dtype=torch.int32, device="cuda")
+    d2 = torch.zeros((2000, 16), device="cuda")
+    _lib.lib().pointops2_set_workspace(None, 0)
+    pointops2_cuda.knnquery_cuda(2000, 16, dev(xyz), dev(nq), off, noff, idx, d2)
+    i_got, d_got = _knn(P, 16, xyz, nq, [8000], [2000])
+    assert np.array_equal(_np(idx), i_got) and np.array_equal(np.sqrt(_np(d2)), d_got)
+    i_ref, d_ref = ref.knnquery(16, xyz, nq, np.array([8000], np.int32), np.array([2000], np.int32))
+    assert np.array_equal(i_got, i_ref) and np.array_equal(d_got, d_ref)

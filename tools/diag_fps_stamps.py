@@ -1,0 +1,10 @@
+import torch, numpy as np, sys
+sys.path.insert(0, '.')
+from stratified_transformer_amd import scene, pointops as P
+xyz = torch.from_numpy(scene.make_room(100000, 0)).cuda()
+off = torch.tensor([100000], dtype=torch.int32, device='cuda')
+for m in (12501, 25001):
+    P.clear_caches()
+    idx = P.furthestsampling(xyz, off, torch.tensor([m], dtype=torch.int32, device='cuda'))
+    torch.cuda.synchronize()
+    print('m', m, 'iters', m - 1)

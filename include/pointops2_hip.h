@@ -182,6 +182,33 @@ void pointops2_set_csc(const int *csc_offsets, const int *csc_pair, const int *c
 void segment_softmax_forward_launcher(int N, int M, int h, const float *src, const int *offsets, float *out);
 void segment_softmax_backward_launcher(int N, int M, int h, const float *out, const float *grad_out,
                                        const int *offsets, float *grad_src);
+/* ---- on-device index build of one stage (model/stratified_transformer.py:10-65, 186-190, 312-317) ----
+ * All arrays are caller-allocated device memory; ws is scratch of pointops2_index_workspace_bytes(N) bytes.
+ *   bbox:       out6 = {min x,y,z, max x,y,z} of xyz [N,3]
+ *   partition:  one grid_sample(): cluster [N] dense window id (torch.unique rank of the voxel id), order [N] point
+ *               ids sorted by (window, id), starts [N+2] bucket boundaries into order, n_windows [1].
+ *               size = window edge, shift = value added to xyz before binning (0, or size/2 for the shifted
+ *               partitions); key_bits = significant bits of the voxel ids (0 = all 64)
+ *   window_coord: wc [N,3] = ((xyz [+ window/2]) - xyz_min) // window  (fp32 floor division), the mask operand of :28-34
+ *   sampled_buckets: the FPS subset (sample_idx [m]) bucketed by a large-window partition: ls [m] point ids in
+ *               (window, id) order, ls_starts [N+1]; `sampled` [N] must be zero-filled by the caller
+ *   pairs_count: offsets [N+1] = exclusive scan of keys per query (offsets[N] = M)
+ *   pairs_fill:  index_0 / index_1 [M], rel_idx [M,3] in the canonical order (dense keys ascending, then
+ *               stratified keys ascending) */
+void pointops2_bbox_launcher(int N, const float *xyz, float *out6);
+size_t pointops2_index_workspace_bytes(int N);
+void pointops2_window_partition_launcher(int N, int b, const float *xyz, const int *offset, const float *bbox6, float size,
+                                         float shift, int key_bits, int *cluster, int *order, int *starts, int *n_windows,
+                                         void *ws, size_t ws_bytes);
+void pointops2_window_coord_launcher(int N, const float *xyz, const float *bbox6, float window, int shifted, float *wc);
+void pointops2_sampled_buckets_launcher(int N, int m, const int *sample_idx, const int *l_order, const int *l_starts,
+                                        const int *l_n_windows, int *sampled, int *ls, int *ls_starts, void *ws, size_t ws_bytes);
+void pointops2_pairs_count_launcher(int N, const int *s_cluster, const int *s_starts, const int *l_cluster, const int *ls,
+                                    const int *ls_starts, const float *wc, int *offsets, void *ws, size_t ws_bytes);
+void pointops2_pairs_fill_launcher(int N, const float *xyz, float window, float quant, const int *s_cluster, const int *s_order,
+                                   const int *s_starts, const int *l_cluster, const int *ls, const int *ls_starts, const float *wc,
+                                   const int *offsets, int *index_0, int *index_1, int *rel_idx);
+
 /* expands CSR offsets to the per-pair query id (index_0) */
 void csr_expand_launcher(int N, int M, const int *offsets, int *index0);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpointops2_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 _lib = None
 
-I, U, P, Z = ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t
+I, U, P, Z, F = ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_float
 
 # name -> argtypes; mirrors include/pointops2_hip.h one to one
 SIGNATURES = {
@@ -53,6 +53,12 @@ SIGNATURES = {
     "segment_softmax_forward_launcher": [I, I, I, P, P, P],
     "segment_softmax_backward_launcher": [I, I, I, P, P, P, P],
     "csr_expand_launcher": [I, I, P, P],
+    "pointops2_bbox_launcher": [I, P, P],
+    "pointops2_window_partition_launcher": [I, I, P, P, P, F, F, I, P, P, P, P, P, Z],
+    "pointops2_window_coord_launcher": [I, P, P, F, I, P],
+    "pointops2_sampled_buckets_launcher": [I, I, P, P, P, P, P, P, P, P, Z],
+    "pointops2_pairs_count_launcher": [I, P, P, P, P, P, P, P, P, Z],
+    "pointops2_pairs_fill_launcher": [I, P, F, F, P, P, P, P, P, P, P, P, P, P, P],
 }
 # entry points with a non-void result
 RESULTS = {
@@ -62,6 +68,7 @@ RESULTS = {
     "pointops2_csc_workspace_bytes": ([I, I], Z),
     "pointops2_fps_workspace_bytes": ([I, I], Z),
     "pointops2_knn_workspace_bytes": ([I, I, I], Z),
+    "pointops2_index_workspace_bytes": ([I], Z),
 }
 
 

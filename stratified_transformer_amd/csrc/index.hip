@@ -1,0 +1,318 @@
+// I3-I5: on-device index build of one Stratified Transformer stage, gfx950.
+//
+// Reproduces bit-exactly, in the canonical (stable-sort) order, what the reference's model code
+// computes with torch ops, [nW,k,k] boolean masks and a 12 M-element sort per block
+// (model/stratified_transformer.py:10-65 grid_sample / get_indice_pairs, :186-190 rel-pos index,
+// :312-317 CSR) — as a handful of streaming kernels with no masks and no pair sort:
+//
+//   partition   voxel id per point with the torch_cluster grid_cluster arithmetic (fp32 subtract,
+//               IEEE divide, truncate), stable radix sort by voxel id => points bucketed by window
+//               with ascending point index inside a bucket, dense window ranks (= torch.unique) by a
+//               boundary scan
+//   pairs       one wavefront per query: dense keys = its small-window bucket; stratified keys = the
+//               FPS-sampled points of its large-window bucket whose fp32 floor-div window coordinate
+//               differs from the query's (wave ballot + prefix popcount keeps them ascending);
+//               counts -> exclusive scan -> CSR offsets; the fill pass writes index_1, index_0 and the
+//               quantised relative position index with torch's own arithmetic (round-half-even,
+//               multiply by the fp32 reciprocal of 1e5 as ATen does for a GPU tensor divided by a
+//               Python scalar, c10::div_floor_floating for `//`).
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace p2 {
+
+// c10::div_floor_floating (torch `//` on floating tensors), fp32
+__device__ __forceinline__ float div_floor(float a, float b) {
+    if (b == 0.f) return __fdiv_rn(a, b);
+    const float mod = fmodf(a, b);
+    float div = __fdiv_rn(__fsub_rn(a, mod), b);
+    if ((mod != 0.f) && ((b < 0.f) != (mod < 0.f))) div = __fsub_rn(div, 1.f);
+    float floordiv;
+    if (div != 0.f) {
+        floordiv = floorf(div);
+        if (__fsub_rn(div, floordiv) > 0.5f) floordiv = __fadd_rn(floordiv, 1.f);
+    } else {
+        floordiv = copysignf(0.f, __fdiv_rn(a, b));
+    }
+    return floordiv;
+}
+
+// ---- global bounding box ---------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bbox_kernel(int N, const float *__restrict__ xyz, float *__restrict__ out6) {
+    __shared__ float red[6][16];
+    const int tid = threadIdx.x;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < N; i += 1024)
+        for (int a = 0; a < 3; a++) {
+            const float v = xyz[(size_t)i * 3 + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    for (int a = 0; a < 3; a++) {
+        for (int st = 1; st < 64; st <<= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], st, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], st, 64));
+        }
+        if ((tid & 63) == 0) { red[a][tid >> 6] = mn[a]; red[3 + a][tid >> 6] = mx[a]; }
+    }
+    __syncthreads();
+    if (tid < 6) {
+        float v = red[tid][0];
+        for (int w = 1; w < 16; w++) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+        out6[tid] = v;
+    }
+}
+
+// ---- partition ---------------------------------------------------------------------------------
+__global__ void voxel_key_kernel(int N, int b, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                 const float *__restrict__ bbox6, float size, float shift,
+                                 unsigned long long *__restrict__ keys, int *__restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int bid = 0;
+    while (bid < b - 1 && i >= offset[bid]) bid++;
+    long long id = 0, mult = 1;
+    for (int a = 0; a < 3; a++) {
+        const float start = bbox6[a];
+        const float end = __fadd_rn(bbox6[3 + a], shift);           // max(xyz + shift): fl() is monotone
+        const float pos = __fadd_rn(xyz[(size_t)i * 3 + a], shift);
+        const long long v = (long long)__fdiv_rn(__fsub_rn(pos, start), size);
+        id += v * mult;
+        mult *= (long long)__fdiv_rn(__fsub_rn(end, start), size) + 1;
+    }
+    id += (long long)bid * mult;  // batch is the 4th coordinate: cell size 1, start 0
+    keys[i] = (unsigned long long)id;
+    vals[i] = i;
+}
+
+__global__ void boundary_flag_kernel(int N, const unsigned long long *__restrict__ skeys, int *__restrict__ flags) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    flags[t] = (t == 0 || skeys[t] != skeys[t - 1]) ? 1 : 0;
+}
+
+__global__ void partition_finish_kernel(int N, const int *__restrict__ order, const int *__restrict__ flags,
+                                        const int *__restrict__ rank_incl, int *__restrict__ cluster,
+                                        int *__restrict__ starts, int *__restrict__ n_windows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const int r = rank_incl[t] - 1;
+    cluster[order[t]] = r;
+    if (flags[t]) starts[r] = t;
+    if (t == N - 1) {
+        starts[r + 1] = N;
+        *n_windows = r + 1;
+    }
+}
+
+// ---- pairs -------------------------------------------------------------------------------------
+__global__ void window_coord_kernel(int N, const float *__restrict__ xyz, const float *__restrict__ bbox6, float window,
+                                    int shifted, float *__restrict__ wc) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * 3) return;
+    const int a = t % 3;
+    float v = xyz[t];
+    if (shifted) v = __fadd_rn(v, __fmul_rn(0.5f, window));  // xyz + 1/2*window_size   (:32)
+    v = __fsub_rn(v, bbox6[a]);                               // - xyz_min
+    wc[t] = div_floor(v, window);                             // // window_size
+}
+
+__global__ void mark_sampled_kernel(int m, const int *__restrict__ sample_idx, int *__restrict__ sampled) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) sampled[sample_idx[t]] = 1;
+}
+__global__ void sampled_in_order_kernel(int N, const int *__restrict__ l_order, const int *__restrict__ sampled, int *__restrict__ flag) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < N) flag[t] = sampled[l_order[t]];
+}
+// compact the sampled points in (large window, point id) order; per-window starts of the compacted list
+__global__ void sampled_compact_kernel(int N, const int *__restrict__ l_order, const int *__restrict__ flag,
+                                       const int *__restrict__ pos_excl, const int *__restrict__ l_starts,
+                                       const int *__restrict__ n_windows, int m_total, int *__restrict__ ls, int *__restrict__ ls_starts) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    if (flag[t]) ls[pos_excl[t]] = l_order[t];
+    const int nw = *n_windows;
+    if (t < nw) ls_starts[t] = pos_excl[l_starts[t]];
+    if (t == 0) ls_starts[nw] = m_total;
+}
+
+__device__ __forceinline__ bool coord_differs(const float *__restrict__ wc, int i, int j) {
+    return wc[(size_t)i * 3] != wc[(size_t)j * 3] || wc[(size_t)i * 3 + 1] != wc[(size_t)j * 3 + 1] ||
+           wc[(size_t)i * 3 + 2] != wc[(size_t)j * 3 + 2];
+}
+
+__global__ __launch_bounds__(256) void pairs_count_kernel(int N, const int *__restrict__ s_cluster, const int *__restrict__ s_starts,
+                                                          const int *__restrict__ l_cluster, const int *__restrict__ ls,
+                                                          const int *__restrict__ ls_starts, const float *__restrict__ wc,
+                                                          int *__restrict__ total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    const int ws = s_cluster[i], wl = l_cluster[i];
+    int cnt = s_starts[ws + 1] - s_starts[ws];
+    const int c0 = ls_starts[wl], c1 = ls_starts[wl + 1];
+    for (int t0 = c0; t0 < c1; t0 += 64) {
+        const int t = t0 + lane;
+        const bool keep = t < c1 && coord_differs(wc, i, ls[t]);
+        cnt += __popcll(__ballot(keep));
+    }
+    if (lane == 0) total[i] = cnt;
+}
+
+__device__ __forceinline__ void write_pair(int i, int j, int at, const float *__restrict__ xyz, float two_w, float quant,
+                                           int *__restrict__ index_0, int *__restrict__ index_1, int *__restrict__ rel_idx) {
+    index_0[at] = i;
+    index_1[at] = j;
+    const float inv = __fdiv_rn(1.0f, 100000.0f);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float r = __fsub_rn(xyz[(size_t)i * 3 + a], xyz[(size_t)j * 3 + a]);  // xyz[index_0] - xyz[index_1]   (:186)
+        r = __fmul_rn(rintf(__fmul_rn(r, 100000.0f)), inv);                   // round(. * 1e5) / 1e5          (:187)
+        r = __fsub_rn(__fadd_rn(r, two_w), 0.0001f);                          // + 2*window_size - 0.0001      (:188)
+        rel_idx[(size_t)at * 3 + a] = (int)div_floor(r, quant);               // // quant_size, .int()
+    }
+}
+
+__global__ __launch_bounds__(256) void pairs_fill_kernel(int N, const float *__restrict__ xyz, float two_w, float quant,
+                                                         const int *__restrict__ s_cluster, const int *__restrict__ s_order,
+                                                         const int *__restrict__ s_starts, const int *__restrict__ l_cluster,
+                                                         const int *__restrict__ ls, const int *__restrict__ ls_starts,
+                                                         const float *__restrict__ wc, const int *__restrict__ offsets,
+                                                         int *__restrict__ index_0, int *__restrict__ index_1, int *__restrict__ rel_idx) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    const int ws = s_cluster[i], wl = l_cluster[i];
+    int at = offsets[i];
+    const int d0 = s_starts[ws], d1 = s_starts[ws + 1];
+    for (int t = d0 + lane; t < d1; t += 64) write_pair(i, s_order[t], at + (t - d0), xyz, two_w, quant, index_0, index_1, rel_idx);
+    at += d1 - d0;
+    const int c0 = ls_starts[wl], c1 = ls_starts[wl + 1];
+    for (int t0 = c0; t0 < c1; t0 += 64) {
+        const int t = t0 + lane;
+        const int j = t < c1 ? ls[t] : 0;
+        const bool keep = t < c1 && coord_differs(wc, i, j);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) write_pair(i, j, at + __popcll(mask & ((1ull << lane) - 1)), xyz, two_w, quant, index_0, index_1, rel_idx);
+        at += __popcll(mask);
+    }
+}
+
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t sort64_bytes(int N) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                             (const int *)nullptr, (int *)nullptr, N, 0, 64, (hipStream_t) nullptr);
+    return bytes;
+}
+static size_t scan_bytes(int N) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (const int *)nullptr, (int *)nullptr, N, (hipStream_t) nullptr);
+    size_t b2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, (const int *)nullptr, (int *)nullptr, N, (hipStream_t) nullptr);
+    return bytes > b2 ? bytes : b2;
+}
+
+}  // namespace p2
+
+using namespace p2;
+
+extern "C" {
+
+void pointops2_bbox_launcher(int N, const float *xyz, float *out6) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(bbox_kernel, dim3(1), dim3(1024), 0, state().stream, N, xyz, out6);
+    check_launch();
+}
+
+size_t pointops2_index_workspace_bytes(int N) {
+    if (N <= 0) return 0;
+    return 2 * al((size_t)N * 8) + 4 * al(((size_t)N + 1) * 4) + al(sort64_bytes(N)) + al(scan_bytes(N + 1));
+}
+
+// key_bits: number of significant bits of the voxel ids (the caller knows the bounding box); 0 = sort all 64
+void pointops2_window_partition_launcher(int N, int b, const float *xyz, const int *offset, const float *bbox6, float size,
+                                         float shift, int key_bits, int *cluster, int *order, int *starts, int *n_windows, void *ws,
+                                         size_t ws_bytes) {
+    if (N <= 0) return;
+    if (ws_bytes < pointops2_index_workspace_bytes(N)) { set_error("pointops2_window_partition: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    char *p = reinterpret_cast<char *>(ws);
+    unsigned long long *keys_in = (unsigned long long *)p; p += al((size_t)N * 8);
+    unsigned long long *keys_out = (unsigned long long *)p; p += al((size_t)N * 8);
+    int *vals_in = (int *)p; p += al(((size_t)N + 1) * 4);
+    int *flags = (int *)p; p += al(((size_t)N + 1) * 4);
+    int *rank = (int *)p; p += al(((size_t)N + 1) * 4);
+    p += al(((size_t)N + 1) * 4);
+    void *tmp = p;
+    size_t tmp_bytes = ws_bytes - (size_t)(p - reinterpret_cast<char *>(ws));
+    const int g = div_up(N, 256);
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(g), dim3(256), 0, st, N, b, xyz, offset, bbox6, size, shift, keys_in, vals_in);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const unsigned long long *)keys_in, keys_out, (const int *)vals_in, order, N,
+                                                      0, (key_bits > 0 && key_bits < 64) ? key_bits : 64, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(boundary_flag_kernel, dim3(g), dim3(256), 0, st, N, keys_out, flags);
+    e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, N, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(partition_finish_kernel, dim3(g), dim3(256), 0, st, N, order, flags, rank, cluster, starts, n_windows);
+    check_launch();
+}
+
+void pointops2_window_coord_launcher(int N, const float *xyz, const float *bbox6, float window, int shifted, float *wc) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(window_coord_kernel, dim3(div_up(N * 3, 256)), dim3(256), 0, state().stream, N, xyz, bbox6, window, shifted, wc);
+    check_launch();
+}
+
+// sampled points of one large-window partition, compacted in (window, point id) order
+void pointops2_sampled_buckets_launcher(int N, int m, const int *sample_idx, const int *l_order, const int *l_starts,
+                                        const int *l_n_windows, int *sampled /*[N] zeroed by the caller*/, int *ls /*[m]*/,
+                                        int *ls_starts /*[N+1]*/, void *ws, size_t ws_bytes) {
+    if (N <= 0) return;
+    if (ws_bytes < pointops2_index_workspace_bytes(N)) { set_error("pointops2_sampled_buckets: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    char *p = reinterpret_cast<char *>(ws);
+    int *flag = (int *)p; p += al(((size_t)N + 1) * 4);
+    int *pos = (int *)p; p += al(((size_t)N + 1) * 4);
+    void *tmp = p;
+    size_t tmp_bytes = ws_bytes - (size_t)(p - reinterpret_cast<char *>(ws));
+    const int g = div_up(N, 256);
+    if (m > 0) hipLaunchKernelGGL(mark_sampled_kernel, dim3(div_up(m, 256)), dim3(256), 0, st, m, sample_idx, sampled);
+    hipLaunchKernelGGL(sampled_in_order_kernel, dim3(g), dim3(256), 0, st, N, l_order, sampled, flag);
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, (const int *)flag, pos, N, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(sampled_compact_kernel, dim3(g), dim3(256), 0, st, N, l_order, flag, pos, l_starts, l_n_windows, m, ls, ls_starts);
+    check_launch();
+}
+
+// pass 1: offsets[N+1] (exclusive scan of the per-query key counts; offsets[N] = M)
+void pointops2_pairs_count_launcher(int N, const int *s_cluster, const int *s_starts, const int *l_cluster, const int *ls,
+                                    const int *ls_starts, const float *wc, int *offsets, void *ws, size_t ws_bytes) {
+    if (N <= 0) return;
+    if (ws_bytes < pointops2_index_workspace_bytes(N)) { set_error("pointops2_pairs_count: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    char *p = reinterpret_cast<char *>(ws);
+    int *total = (int *)p; p += al(((size_t)N + 1) * 4);
+    void *tmp = p;
+    size_t tmp_bytes = ws_bytes - (size_t)(p - reinterpret_cast<char *>(ws));
+    (void)hipMemsetAsync(total + N, 0, sizeof(int), st);
+    hipLaunchKernelGGL(pairs_count_kernel, dim3(div_up(N, 4)), dim3(256), 0, st, N, s_cluster, s_starts, l_cluster, ls, ls_starts, wc, total);
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, (const int *)total, offsets, N + 1, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    check_launch();
+}
+
+// pass 2: index_0 / index_1 [M], rel_idx [M,3]
+void pointops2_pairs_fill_launcher(int N, const float *xyz, float window, float quant, const int *s_cluster, const int *s_order,
+                                   const int *s_starts, const int *l_cluster, const int *ls, const int *ls_starts, const float *wc,
+                                   const int *offsets, int *index_0, int *index_1, int *rel_idx) {
+    if (N <= 0) return;
+    // 2 * self.window_size is a Python float product rounded to fp32 when added to the tensor (:188)
+    const float two_w = (float)(2.0 * (double)window);
+    hipLaunchKernelGGL(pairs_fill_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, xyz, two_w, quant, s_cluster, s_order, s_starts,
+                       l_cluster, ls, ls_starts, wc, offsets, index_0, index_1, rel_idx);
+    check_launch();
+}
+
+}  // extern "C"

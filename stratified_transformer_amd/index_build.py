@@ -167,3 +167,79 @@ def stage_partitions(xyz, offset, window_size):
         "large": partition(xyz, batch, 2 * ws, None),
         "large_shift": partition(xyz + 1 / 2 * (2 * ws), batch, 2 * ws, xyz_min),
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# native path (csrc/index.hip): same outputs, HIP kernels, two host syncs per stage
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class HipPartition:
+    cluster: torch.Tensor    # [N] i32
+    order: torch.Tensor      # [N] i32
+    starts: torch.Tensor     # [N+2] i32
+    n_windows: torch.Tensor  # [1] i32 (device)
+
+
+def _f32(x):
+    import numpy as np
+    return float(np.float32(x))
+
+
+def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx):
+    """Even and odd block index of one stage, built by the HIP kernels of csrc/index.hip.
+
+    xyz [N,3] f32 (GPU), offset [b] i32, downsample_idx [m] i32 -> (BlockIndex even, BlockIndex odd),
+    bit-identical to build_block_index() on the same inputs."""
+    import numpy as np
+    from . import _lib
+    from ._lib import ptr
+    assert xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous()
+    N, b, dev = xyz.shape[0], offset.shape[0], xyz.device
+    m = int(downsample_idx.shape[0])
+    l = _lib.lib()
+    w32 = np.float32(window_size)
+    i32 = dict(dtype=torch.int32, device=dev)
+
+    def call(name, *args):
+        _lib.call(name, *args, device=dev)
+
+    with torch.cuda.device(dev):
+        ws_bytes = int(l.pointops2_index_workspace_bytes(N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        bbox = torch.empty(6, dtype=torch.float32, device=dev)
+        call("pointops2_bbox_launcher", N, ptr(xyz), ptr(bbox))
+        bb = np.asarray(bbox.tolist(), dtype=np.float32)   # host sync 1: sizes the radix-sort key
+        parts = {}
+        for name, size, shift in (("small", w32, np.float32(0)), ("small_shift", w32, np.float32(0.5) * w32),
+                                  ("large", np.float32(2) * w32, np.float32(0)), ("large_shift", np.float32(2) * w32, w32)):
+            nvox = 1
+            for a in range(3):
+                nvox *= int((np.float32(bb[3 + a] + shift) - bb[a]) / size) + 1
+            key_bits = max(int(nvox * b).bit_length() + 1, 8)
+            part = HipPartition(torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N + 2, **i32), torch.empty(1, **i32))
+            call("pointops2_window_partition_launcher", N, b, ptr(xyz), ptr(offset), ptr(bbox), float(size), float(shift), key_bits,
+                 ptr(part.cluster), ptr(part.order), ptr(part.starts), ptr(part.n_windows), ptr(ws), ws_bytes)
+            parts[name] = part
+        sampled = torch.zeros(N, **i32)
+        out = []
+        pending = []
+        for shifted, sname, lname in ((0, "small", "large"), (1, "small_shift", "large_shift")):
+            s, lg = parts[sname], parts[lname]
+            ls, ls_starts = torch.empty(max(m, 1), **i32), torch.empty(N + 1, **i32)
+            call("pointops2_sampled_buckets_launcher", N, m, ptr(downsample_idx), ptr(lg.order), ptr(lg.starts), ptr(lg.n_windows),
+                 ptr(sampled), ptr(ls), ptr(ls_starts), ptr(ws), ws_bytes)
+            wc = torch.empty((N, 3), dtype=torch.float32, device=dev)
+            call("pointops2_window_coord_launcher", N, ptr(xyz), ptr(bbox), float(w32), shifted, ptr(wc))
+            offsets = torch.empty(N + 1, **i32)
+            call("pointops2_pairs_count_launcher", N, ptr(s.cluster), ptr(s.starts), ptr(lg.cluster), ptr(ls), ptr(ls_starts), ptr(wc),
+                 ptr(offsets), ptr(ws), ws_bytes)
+            pending.append((s, lg, ls, ls_starts, wc, offsets))
+        totals = torch.stack([p[5][N] for p in pending]).tolist()   # host sync 2: M of both patterns
+        for (s, lg, ls, ls_starts, wc, offsets), M in zip(pending, totals):
+            index_0, index_1 = torch.empty(M, **i32), torch.empty(M, **i32)
+            rel = torch.empty((M, 3), **i32)
+            call("pointops2_pairs_fill_launcher", N, ptr(xyz), float(w32), _f32(quant_size), ptr(s.cluster), ptr(s.order), ptr(s.starts),
+                 ptr(lg.cluster), ptr(ls), ptr(ls_starts), ptr(wc), ptr(offsets), ptr(index_0), ptr(index_1), ptr(rel))
+            counts = offsets[1:] - offsets[:-1]
+            out.append(BlockIndex(index_0, index_1, offsets, counts.max(), rel, None))
+    return out[0], out[1], parts

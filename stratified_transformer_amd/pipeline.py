@@ -123,10 +123,13 @@ def attention_block(state, blk, timer):
     return out
 
 
-def stage_index_build(xyz, offset, offset_host, st, cfg, timer):
-    parts = timer.run("index/partition", index_build.stage_partitions, xyz, offset, st.window_size)
+def stage_index_build(xyz, offset, offset_host, st, cfg, timer, use_hip=True):
     new_offset = torch.tensor(index_build.stratified_new_offset(offset_host, cfg.downsample_scale), dtype=torch.int32, device=xyz.device)
     ds = timer.run("fps/stratified", P.furthestsampling, xyz, offset, new_offset)
+    if use_hip:
+        even, odd, _ = timer.run("index/build", index_build.stage_index_hip, xyz, offset, st.window_size, st.quant_size, ds)
+        return even, odd, ds
+    parts = timer.run("index/partition", index_build.stage_partitions, xyz, offset, st.window_size)
     even = timer.run("index/pairs", index_build.build_block_index, xyz, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)
     odd = timer.run("index/pairs", index_build.build_block_index, xyz, parts["small_shift"], parts["large_shift"], ds, st.window_size, st.quant_size, True)
     return even, odd, ds

@@ -385,3 +385,49 @@ def test_knn_grid_path_ties_outliers_and_scan_agree(P):
     assert np.array_equal(_np(idx), i_got) and np.array_equal(np.sqrt(_np(d2)), d_got)
     i_ref, d_ref = ref.knnquery(16, xyz, nq, np.array([8000], np.int32), np.array([2000], np.int32))
     assert np.array_equal(i_got, i_ref) and np.array_equal(d_got, d_ref)
+
+
+# ---- on-device index build (csrc/index.hip) vs the reference's golden tensors and the oracle --------
+def test_index_build_hip_matches_reference_golden(golden):
+    from stratified_transformer_amd import index_build
+    xyz = dev(golden["xyz"])
+    even, odd, parts = index_build.stage_index_hip(xyz, dev(golden["offset"]), float(golden["window_size"]), float(golden["quant_size"]),
+                                                   dev(golden["downsample_idx"]))
+    for name, part in parts.items():
+        assert np.array_equal(_np(part.cluster), golden[f"grid_{name}_cluster"]), name
+        nw = int(part.n_windows)
+        counts = np.diff(_np(part.starts)[: nw + 1])
+        assert np.array_equal(counts, golden[f"grid_{name}_counts"]), name
+        p2v = golden[f"grid_{name}_p2v"]
+        order = _np(part.order)
+        assert np.array_equal(order, np.concatenate([p2v[w, :c] for w, c in enumerate(counts)])), name
+    for i, blk in enumerate((even, odd)):
+        assert np.array_equal(_np(blk.index_0), golden[f"blk{i}_index_0"])
+        assert np.array_equal(_np(blk.index_1), golden[f"blk{i}_index_1"])
+        assert np.array_equal(_np(blk.offsets), golden[f"blk{i}_offsets"])
+        assert int(blk.n_max) == int(golden[f"blk{i}_n_max"])
+        # the golden rel_idx is CPU-torch arithmetic (true division by 1e5); the GPU's reciprocal multiply may flip rare floors
+        assert (_np(blk.rel_idx) != golden[f"blk{i}_rel_idx_cpu"]).mean() < 1e-3
+
+
+@pytest.mark.parametrize("n,nbatch,w,quant", [(6000, 1, 0.16, 0.01), (5000, 3, 0.32, 0.02), (900, 2, 0.64, 0.04)])
+def test_index_build_hip_matches_oracle_and_torch_path(n, nbatch, w, quant):
+    from oracle import index_ref
+    from stratified_transformer_amd import index_build, scene
+    sizes = [n // nbatch + (1 if i < n % nbatch else 0) for i in range(nbatch)]
+    xyz_np, offset = scene.make_batch(sizes, seed=n)
+    rng = np.random.default_rng(n)
+    ds = np.sort(rng.permutation(n)[: n // 8 + nbatch]).astype(np.int32)
+    xyz = dev(xyz_np)
+    even, odd, _ = index_build.stage_index_hip(xyz, dev(offset), w, quant, dev(ds))
+    x_cpu = torch.from_numpy(xyz_np)
+    parts = index_build.stage_partitions(xyz, dev(offset), w)            # torch-op path on the same device
+    for par, blk in enumerate((even, odd)):
+        want = index_ref.build_stage_indices(x_cpu, offset, w, quant, torch.from_numpy(ds), par, div_mode="cuda")
+        assert np.array_equal(_np(blk.index_1), want["index_1"].numpy())
+        assert np.array_equal(_np(blk.offsets), want["offsets"].numpy())
+        assert np.array_equal(_np(blk.rel_idx), want["rel_idx"].numpy())
+        assert np.array_equal(_np(blk.index_0), want["index_0"].numpy())
+        s, l = ("small", "large") if par == 0 else ("small_shift", "large_shift")
+        tb = index_build.build_block_index(xyz, parts[s], parts[l], dev(ds), w, quant, par == 1)
+        assert torch.equal(tb.index_1, blk.index_1) and torch.equal(tb.rel_idx, blk.rel_idx) and torch.equal(tb.offsets, blk.offsets)

@@ -233,6 +233,7 @@ def main():
                                    "unit = index build + FPS + depth x (A1,A2,add,A3,A4 fwd+bwd) + TransitionDown FPS/kNN16 + Upsample kNN3 per stage",
                        "points_per_gpu": N_POINTS, "pairs_stage0": run["results"][0]["M_even"],
                        "stage_points": [r["n"] for r in run["results"]], "parallelism": "1 scene per rank, no data-path collective"},
+            "overlap": "geometry chain (FPS, gather, kNN) on a side stream beside index build + attention; components_ms_per_step are per-op device times and overlap in wall time",
             "roofline": roofline(comp, run),
             "components_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(comp.items())},
         }

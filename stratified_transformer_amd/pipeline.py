@@ -123,64 +123,107 @@ def attention_block(state, blk, timer):
     return out
 
 
-def stage_index_build(xyz, offset, offset_host, st, cfg, timer, use_hip=True):
-    new_offset = torch.tensor(index_build.stratified_new_offset(offset_host, cfg.downsample_scale), dtype=torch.int32, device=xyz.device)
-    ds = timer.run("fps/stratified", P.furthestsampling, xyz, offset, new_offset)
-    if use_hip:
-        even, odd, _ = timer.run("index/build", index_build.stage_index_hip, xyz, offset, st.window_size, st.quant_size, ds)
-        return even, odd, ds
-    parts = timer.run("index/partition", index_build.stage_partitions, xyz, offset, st.window_size)
-    even = timer.run("index/pairs", index_build.build_block_index, xyz, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)
-    odd = timer.run("index/pairs", index_build.build_block_index, xyz, parts["small_shift"], parts["large_shift"], ds, st.window_size, st.quant_size, True)
-    return even, odd, ds
+def _offsets_tensor(values, device):
+    t = torch.tensor(values, dtype=torch.int32, device=device)
+    P.hint_host_offsets(t, values)
+    return t
 
 
-def transition_down(xyz, offset, offset_host, cfg, timer):
-    """TransitionDown.forward's sampling + grouping indices (:98-106) -> next stage's xyz/offset, knn idx"""
-    n_off_host = index_build.transition_down_offset(offset_host, cfg.ratio)
-    n_offset = torch.tensor(n_off_host, dtype=torch.int32, device=xyz.device)
-    idx = timer.run("fps/transition", P.furthestsampling, xyz, offset, n_offset)
-    n_xyz = xyz[idx.long(), :].contiguous()
-    knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, xyz, n_xyz, offset, n_offset)
-    return n_xyz, n_offset, n_off_host, knn_idx
+_GEO_STREAMS = {}
 
 
-def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0):
+def geometry_stream(device):
+    """Side stream for the geometry chain (FPS -> gather -> kNN): sequential by nature and one CU wide,
+    so it runs BESIDE the attention blocks of the main stream instead of in front of them."""
+    key = torch.device(device).index
+    if key not in _GEO_STREAMS:
+        _GEO_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _GEO_STREAMS[key]
+
+
+def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True):
     """Runs the whole unit once.  `states` (list of StageState) carries the resident synthetic tensors;
-    pass None on the first call to have them created (not timed by bench.py).  Returns (states, results)."""
+    pass None on the first call to have them created (not timed by bench.py).  Returns (states, results).
+
+    overlap=True: the geometry chain of all stages (stratified FPS, its continuation to the TransitionDown
+    sample count, the gather of the next stage's points, kNN-16, kNN-3) is enqueued on a side stream; the
+    main stream (index build + attention forward/backward) only waits for the first n//scale+1 samples of
+    its own stage.  Nothing is skipped and every dependency is an event; results are identical."""
     timer = timer or Timer(False)
     # nothing is carried over from an earlier pass: the CSC transpositions and the FPS sampler state are
     # rebuilt inside every pass (they are reused only WITHIN a pass, between blocks / the two FPS calls of a stage)
     P.clear_caches()
+    dev = xyz.device
+    main = torch.cuda.current_stream(dev)
+    geo = geometry_stream(dev) if overlap else main
+    if overlap:
+        geo.wait_stream(main)
     offset_host = [int(o) for o in offset.tolist()]
+    P.hint_host_offsets(offset, offset_host)
     make = states is None
     states = [] if make else states
     results = []
-    cur_xyz, cur_off, cur_off_host = xyz, offset, offset_host
     first = 0 if cfg.stem_transformer else 1
+
+    def on_geo():
+        return torch.cuda.stream(geo)
+
+    def transition(x, off, off_host):
+        """TransitionDown's sampling + grouping indices (:98-106), on the geometry stream"""
+        n_off_host = index_build.transition_down_offset(off_host, cfg.ratio)
+        n_offset = _offsets_tensor(n_off_host, dev)
+        idx = timer.run("fps/transition", P.furthestsampling, x, off, n_offset)
+        n_xyz = x[idx.long(), :].contiguous()
+        knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, x, n_xyz, off, n_offset)
+        return n_xyz, n_offset, n_off_host, knn_idx
+
+    cur_xyz, cur_off, cur_off_host = xyz, offset, offset_host
     if not cfg.stem_transformer:  # Stratified.forward :458-462: a TransitionDown precedes the first attention stage
-        cur_xyz, cur_off, cur_off_host, _ = transition_down(cur_xyz, cur_off, cur_off_host, cfg, timer)
+        with on_geo():
+            cur_xyz, cur_off, cur_off_host, _ = transition(cur_xyz, cur_off, cur_off_host)
     stack = []
     for si in range(first, len(cfg.stages)):
         st = cfg.stages[si]
+        # ---- geometry stream: samples for this stage's stratified keys, then on to the next stage ----
+        with on_geo():
+            new_offset = _offsets_tensor(index_build.stratified_new_offset(cur_off_host, cfg.downsample_scale), dev)
+            ds = timer.run("fps/stratified", P.furthestsampling, cur_xyz, cur_off, new_offset)
+            ev_ds = torch.cuda.Event()
+            ev_ds.record(geo)
+            nxt = None
+            if si < len(cfg.stages) - 1:
+                nxt = transition(cur_xyz, cur_off, cur_off_host)
+        # ---- main stream: index build + attention of this stage ----
+        if overlap:
+            main.wait_event(ev_ds)
+            for t in (ds, cur_xyz, cur_off):
+                t.record_stream(main)
         if make:
             states.append(make_stage_state(cur_xyz, cur_off, st, seed + si))
         state = states[si - first]
         state.xyz, state.offset = cur_xyz, cur_off
-        even, odd, ds = stage_index_build(cur_xyz, cur_off, cur_off_host, st, cfg, timer)
+        if use_hip_index:
+            even, odd, _ = timer.run("index/build", index_build.stage_index_hip, cur_xyz, cur_off, st.window_size, st.quant_size, ds)
+        else:
+            parts = timer.run("index/partition", index_build.stage_partitions, cur_xyz, cur_off, st.window_size)
+            even = timer.run("index/pairs", index_build.build_block_index, cur_xyz, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)
+            odd = timer.run("index/pairs", index_build.build_block_index, cur_xyz, parts["small_shift"], parts["large_shift"], ds, st.window_size, st.quant_size, True)
         out = None
         for b in range(st.depth):
             out = attention_block(state, even if b % 2 == 0 else odd, timer)
         results.append(dict(stage=si, n=cur_xyz.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),
                             even=even, odd=odd, downsample_idx=ds, out=out))
         stack.append((cur_xyz, cur_off))
-        if si < len(cfg.stages) - 1:
-            cur_xyz, cur_off, cur_off_host, knn_idx = transition_down(cur_xyz, cur_off, cur_off_host, cfg, timer)
+        if nxt is not None:
+            cur_xyz, cur_off, cur_off_host, knn_idx = nxt
             results[-1]["transition_knn"] = knn_idx
     # Upsample chain (:479-480): interpolate from the coarse stage back to each finer one (kNN k=up_k)
-    coarse_xyz, coarse_off = stack.pop()
-    while stack:
-        fine_xyz, fine_off = stack.pop()
-        timer.run("knn/k3", P.knnquery, cfg.up_k, coarse_xyz, fine_xyz, coarse_off, fine_off)
-        coarse_xyz, coarse_off = fine_xyz, fine_off
+    with on_geo():
+        coarse_xyz, coarse_off = stack.pop()
+        while stack:
+            fine_xyz, fine_off = stack.pop()
+            timer.run("knn/k3", P.knnquery, cfg.up_k, coarse_xyz, fine_xyz, coarse_off, fine_off)
+            coarse_xyz, coarse_off = fine_xyz, fine_off
+    if overlap:
+        main.wait_stream(geo)
     return states, results

@@ -86,6 +86,7 @@ def csc_of(index0_offsets, index1, n_keys):
 def clear_caches():
     _CSC_CACHE.clear()
     _FPS_CACHE.clear()
+    _HOST_OFFSETS.clear()
 
 
 class _with_csc:
@@ -105,6 +106,20 @@ class _with_csc:
 # ---------------------------------------------------------------------------------------------
 _FPS_CACHE = OrderedDict()
 _FPS_CACHE_SIZE = 4
+_HOST_OFFSETS = {}
+
+
+def hint_host_offsets(tensor, values):
+    """Tell the sampler the host copy of a (device) offset tensor, so that it need not read it back
+    (a D2H copy synchronises the stream, which defeats running the sampler beside other work)."""
+    _HOST_OFFSETS[(tensor.data_ptr(), tensor._version)] = ([int(v) for v in values], tensor)
+    while len(_HOST_OFFSETS) > 64:
+        _HOST_OFFSETS.pop(next(iter(_HOST_OFFSETS)))
+
+
+def _host_list(t):
+    hit = _HOST_OFFSETS.get((t.data_ptr(), t._version))
+    return hit[0] if hit is not None else None
 
 
 class FurthestSampling(Function):
@@ -118,8 +133,9 @@ class FurthestSampling(Function):
         a repeated or shorter request is served from it, a longer one resumes it."""
         assert xyz.is_contiguous()
         n, b = xyz.shape[0], offset.shape[0]
-        host = torch.stack([offset, new_offset]).tolist()  # one D2H copy (the reference loops .item(), :22-25)
-        offs, new_offs = host
+        offs, new_offs = _host_list(offset), _host_list(new_offset)
+        if offs is None or new_offs is None:
+            offs, new_offs = torch.stack([offset, new_offset]).tolist()  # one D2H copy (the reference loops .item(), :22-25)
         n_max = offs[0]
         for i in range(1, b):
             n_max = max(offs[i] - offs[i - 1], n_max)

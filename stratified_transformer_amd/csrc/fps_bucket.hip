@@ -44,7 +44,9 @@ __device__ __forceinline__ float sqd(float dx, float dy, float dz) {
 // dependent ds_bpermute round trips, and the 64-bit key would double that)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_step(unsigned v) {
-    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+    // old = 0 (identity of unsigned max) + bound_ctrl: rows masked off / lanes without a source read 0, which
+    // lets the DPP combiner fold the move into v_max_u32_dpp (one instruction per step)
+    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
     return v > t ? v : t;
 }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
@@ -55,6 +57,14 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = dpp_step<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
     v = dpp_step<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3: lane 63 holds the wave max
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// maximum over lanes 0..15 only (values in the first row): four row steps, result in every lane of row 0
+__device__ __forceinline__ unsigned row0_max_u32(unsigned v) {
+    v = dpp_step<0xB1, 0xF>(v);
+    v = dpp_step<0x4E, 0xF>(v);
+    v = dpp_step<0x141, 0xF>(v);
+    v = dpp_step<0x140, 0xF>(v);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 // max of (hi:lo) keys: max hi first, then max lo among the lanes that hold it
 __device__ __forceinline__ unsigned long long wmax64(unsigned long long v) {
@@ -280,16 +290,25 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
     const int first = done == 0 ? start_n : idx[start_m + done - 1];
     float x1 = xyz[(size_t)first * 3 + 0], y1 = xyz[(size_t)first * 3 + 1], z1 = xyz[(size_t)first * 3 + 2];
 
-    // the wave's best bucket, kept wave-uniform between steps; recomputed only after an update
+    // the wave's best bucket, kept wave-uniform between steps: key, coordinates and which owned bucket holds
+    // it (code = slot*64 + lane).  Keys only decrease, so it changes only when the holder itself is updated.
     unsigned long long wk = 0ull;
     float wx = 0.f, wy = 0.f, wz = 0.f;
-    bool dirty = true;
+    int whold = -1;
+    bool recompute = true;
 
-    int par = 0;
-    for (int j = start_m + max(done, 1); j < end_m; j++, par ^= 1) {
+    auto update_regs = [&](int code, const KeyMax &km, float cx, float cy, float cz) {
+#pragma unroll
+        for (int s = 0; s < NBL; s++)
+            if ((code >> 6) == s && lane == (code & 63)) { key[s] = km.key; bx[s] = cx; by[s] = cy; bz[s] = cz; }
+        if (code == whold) recompute = true;
+    };
+
+    for (int j = start_m + max(done, 1); j < end_m; j++) {
         if (STAMP) t_a = __builtin_amdgcn_s_memtime();
         unsigned long long hm[NBL];
         unsigned long long any = 0ull;
+        int ntouched = 0;
 #pragma unroll
         for (int s = 0; s < NBL; s++) {
             const float dx = fmaxf(fmaxf(mnx[s] - x1, x1 - mxx[s]), 0.f);
@@ -297,9 +316,31 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             const float dz = fmaxf(fmaxf(mnz[s] - z1, z1 - mxz[s]), 0.f);
             hm[s] = __ballot(sqd(dx, dy, dz) < __uint_as_float((unsigned)(key[s] >> 32)));
             any |= hm[s];
+            ntouched += __popcll(hm[s]);
+        }
+        if (STAMP) n_upd += ntouched;
+        if (ntouched == 1 && BSZ == 64) {
+            // the common case: exactly one owned bucket to update, straight-line
+            int code = -1;
+#pragma unroll
+            for (int s = 0; s < NBL; s++)
+                if (hm[s]) code = s * 64 + __ffsll(hm[s]) - 1;
+            const int pos = start_n + (code * NW + wave) * 64 + lane;
+            unsigned long long k = 0ull;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < end_n) {
+                p = pts[pos];
+                const unsigned rk = rank[pos];
+                const float d = sqd(p.x - x1, p.y - y1, p.z - z1);
+                const float d2 = fminf(d, p.w);
+                if (d2 != p.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
+                k = ((unsigned long long)__float_as_uint(d2) << 32) | rk;
+            }
+            const KeyMax km = wave_key_max(k);
+            update_regs(code, km, rl(p.x, km.lane), rl(p.y, km.lane), rl(p.z, km.lane));
+            any = 0ull;
         }
         while (any) {
-            dirty = true;
             // next (up to) four touched buckets across all slots: code = slot*64 + owner lane, -1 = none
             int code[4];
             any = 0ull;
@@ -315,7 +356,6 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             }
 #pragma unroll
             for (int s = 0; s < NBL; s++) any |= hm[s];
-            if (STAMP) n_upd += (code[0] >= 0) + (code[1] >= 0) + (code[2] >= 0) + (code[3] >= 0);
             if (BSZ == 64) {
                 // all loads first (kept in flight together), then one reduction per touched bucket
                 float4 p[4];
@@ -340,10 +380,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
                         k = ((unsigned long long)__float_as_uint(d2) << 32) | rk[u];
                     }
                     const KeyMax km = wave_key_max(k);
-                    const float cx = rl(p[u].x, km.lane), cy = rl(p[u].y, km.lane), cz = rl(p[u].z, km.lane);
-#pragma unroll
-                    for (int s = 0; s < NBL; s++)
-                        if ((code[u] >> 6) == s && lane == (code[u] & 63)) { key[s] = km.key; bx[s] = cx; by[s] = cy; bz[s] = cz; }
+                    update_regs(code[u], km, rl(p[u].x, km.lane), rl(p[u].y, km.lane), rl(p[u].z, km.lane));
                 }
             } else {
 #pragma unroll
@@ -362,38 +399,62 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
                         if (k > best) { best = k; cx = q.x; cy = q.y; cz = q.z; }
                     }
                     const KeyMax km = wave_key_max(best);
-                    const float ux = rl(cx, km.lane), uy = rl(cy, km.lane), uz = rl(cz, km.lane);
-#pragma unroll
-                    for (int s = 0; s < NBL; s++)
-                        if ((code[u] >> 6) == s && lane == (code[u] & 63)) { key[s] = km.key; bx[s] = ux; by[s] = uy; bz[s] = uz; }
+                    update_regs(code[u], km, rl(cx, km.lane), rl(cy, km.lane), rl(cz, km.lane));
                 }
             }
         }
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_test += t_b - t_a; t_a = t_b; }
-        if (dirty) {  // wave-uniform
+        if (recompute) {  // wave-uniform
             unsigned long long mk = key[0];
             float mx_ = bx[0], my_ = by[0], mz_ = bz[0];
+            int ms = 0;
 #pragma unroll
             for (int s = 1; s < NBL; s++)
-                if (key[s] > mk) { mk = key[s]; mx_ = bx[s]; my_ = by[s]; mz_ = bz[s]; }
+                if (key[s] > mk) { mk = key[s]; mx_ = bx[s]; my_ = by[s]; mz_ = bz[s]; ms = s; }
             const KeyMax wm = wave_key_max(mk);
             wk = wm.key;
             wx = rl(mx_, wm.lane); wy = rl(my_, wm.lane); wz = rl(mz_, wm.lane);
-            dirty = false;
-        }
-        if (lane == 0) {
-            wkey[par][wave] = wk;
-            wbest[par][wave] = make_float4(wx, wy, wz, 0.f);
+            whold = __builtin_amdgcn_readlane(ms, wm.lane) * 64 + wm.lane;
+            recompute = false;
+            if (lane == 0) {
+                wkey[0][wave] = wk;
+                wbest[0][wave] = make_float4(wx, wy, wz, 0.f);
+            }
         }
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_red += t_b - t_a; t_a = t_b; }
-        lds_barrier();
+        lds_barrier();  // every wave's slot is current
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_bar += t_b - t_a; t_a = t_b; }
-        const int src = lane < NW ? lane : 0;
-        const unsigned long long gk = wkey[par][src];
-        const float4 gc = wbest[par][src];
-        const KeyMax gm = wave_key_max(lane < NW ? gk : 0ull);
-        x1 = rl(gc.x, gm.lane); y1 = rl(gc.y, gm.lane); z1 = rl(gc.z, gm.lane);
-        if (tid == 0) idx[j] = start_n + rel_of(gm.key, Bref, log2B);
+        if (wave == 0) {
+            // arg-max over the NW slots (one wave, so the others do not compete for issue slots)
+            const int src = lane < NW ? lane : 0;
+            const unsigned long long gk = lane < NW ? wkey[0][src] : 0ull;
+            const float4 gc = wbest[0][src];
+            KeyMax gm;
+            if (NW <= 16) {
+                const unsigned hi = (unsigned)(gk >> 32), lo = (unsigned)gk;
+                const unsigned mh = row0_max_u32(hi);
+                const unsigned long long tied = __ballot(hi == mh && lane < NW);
+                if (__popcll(tied) == 1) {
+                    gm.lane = __ffsll(tied) - 1;
+                    gm.key = ((unsigned long long)mh << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, gm.lane);
+                } else {
+                    const unsigned ml = row0_max_u32((hi == mh && lane < NW) ? lo : 0u);
+                    gm.key = ((unsigned long long)mh << 32) | ml;
+                    gm.lane = __ffsll((unsigned long long)__ballot(hi == mh && lo == ml && lane < NW)) - 1;
+                }
+            } else {
+                gm = wave_key_max(gk);
+            }
+            if (lane == 0) {
+                wbest[1][0] = make_float4(rl(gc.x, gm.lane), rl(gc.y, gm.lane), rl(gc.z, gm.lane), 0.f);
+                idx[j] = start_n + rel_of(gm.key, Bref, log2B);
+            }
+        }
+        lds_barrier();  // the new sample is published
+        {
+            const float4 ns = wbest[1][0];
+            x1 = ns.x; y1 = ns.y; z1 = ns.z;
+        }
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_fin += t_b - t_a; }
     }
     if (STAMP && dbg && lane == 0) {

@@ -176,6 +176,10 @@ void pointops2_csc_build(int N, int M, const int *index0_offsets, const int *ind
                          int *csc_offsets, int *csc_pair, int *csc_query,
                          void *workspace, size_t workspace_bytes);
 void pointops2_set_csc(const int *csc_offsets, const int *csc_pair, const int *csc_query);
+/* Rows of k / v when they outnumber the CSR's query rows N (a rank of a sharded scene holds all keys but only
+ * its own queries); read by pointops2_csc_build (then csc_offsets has n+1 entries) and by the *_backward_*
+ * launchers' key-side kernels.  0 (default) = N, the reference's implicit assumption. */
+void pointops2_set_key_rows(int n);
 
 /* torch_scatter.scatter_softmax(src [M,h], index_0, dim=0) over CSR segments
  * (model/stratified_transformer.py:205) and its backward. */

@@ -96,7 +96,7 @@ def attention_step1_v2(q, k, index1, index0_offsets):
     N, h, d = q.shape
     M = index1.shape[0]
     out = np.zeros((M, h), dtype=np.float32)
-    lib().oracle_attention_step1_forward_v2(k.shape[0], M, h, h * d, _p(q), _p(k), _p(index0_offsets), _p(index1), _p(out))
+    lib().oracle_attention_step1_forward_v2(index0_offsets.shape[0] - 1, M, h, h * d, _p(q), _p(k), _p(index0_offsets), _p(index1), _p(out))
     return out
 
 
@@ -191,7 +191,8 @@ def attention_step2_with_rel_pos_value_v2(attn, v, index0_offsets, index1, table
     attn, v, table = _f(attn), _f(v), _f(table)
     index0_offsets, index1, rel_idx = _i(index0_offsets), _i(index1), _i(rel_idx)
     M, h = attn.shape
-    N, _, d = v.shape
+    d = v.shape[2]
+    N = index0_offsets.shape[0] - 1  # CSR rows (queries); v may have more rows (keys)
     out = np.zeros((N, h, d), dtype=np.float32)
     lib().oracle_attention_step2_with_rel_pos_value_forward_v2(N, M, h, d, _p(attn), _p(v), _p(index0_offsets), _p(index1), _p(table), _p(rel_idx), _p(out))
     return out
@@ -201,7 +202,8 @@ def attention_step2_with_rel_pos_value_v2_backward(grad_out, attn, v, index0_off
     grad_out, attn, v, table = _f(grad_out), _f(attn), _f(v), _f(table)
     index0_offsets, index1, rel_idx = _i(index0_offsets), _i(index1), _i(rel_idx)
     M, h = attn.shape
-    N, _, d = v.shape
+    d = v.shape[2]
+    N = index0_offsets.shape[0] - 1
     L = table.shape[0]
     ga, gv, gt = np.zeros_like(attn), np.zeros_like(v), np.zeros_like(table)
     lib().oracle_attention_step2_with_rel_pos_value_backward_v2(N, M, h, d, L, _p(grad_out), _p(index0_offsets), _p(index1), _p(attn), _p(v),

@@ -23,6 +23,7 @@ SIGNATURES = {
     "pointops2_set_workspace": [P, Z],
     "pointops2_set_point_count": [I],
     "pointops2_set_batch_count": [I],
+    "pointops2_set_key_rows": [I],
     "pointops2_set_fps_resume": [P, P],
     "pointops2_set_csc": [P, P, P],
     "pointops2_csc_build": [I, I, P, P, P, P, P, P, Z],

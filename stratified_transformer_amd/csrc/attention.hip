@@ -238,9 +238,11 @@ void attention_step1_backward_cuda_launcher_v2(int N, int M, int h, int C, const
         constexpr int D = decltype(dtag)::value;
         hipLaunchKernelGGL((gather_accum_kernel<D, false>), dim3(blocks), dim3(256), 0, st, N, h, index0_offsets,
                            index1, (const int *)nullptr, grad_out, k, grad_q);
-        if (co)
-            hipLaunchKernelGGL((gather_accum_kernel<D, true>), dim3(blocks), dim3(256), 0, st, N, h, co, cq, cp,
+        if (co) {
+            const int NK = ls.key_rows > 0 ? ls.key_rows : N;
+            hipLaunchKernelGGL((gather_accum_kernel<D, true>), dim3(div_up(NK, 4)), dim3(256), 0, st, NK, h, co, cq, cp,
                                grad_out, q, grad_k);
+        }
         else
             hipLaunchKernelGGL(scatter_atomic_kernel<D>, dim3(blocks), dim3(256), 0, st, N, h, index0_offsets,
                                index1, grad_out, q, grad_k);

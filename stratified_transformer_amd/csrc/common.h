@@ -17,6 +17,7 @@ struct LaunchState {
     const int *csc_query = nullptr;
     int total_points = 0;  // pointops2_set_point_count: N of the next furthestsampling / knnquery call (0 = unknown)
     int batch_count = 0;   // pointops2_set_batch_count: b of the next knnquery call (0 = unknown)
+    int key_rows = 0;      // pointops2_set_key_rows: rows of k / v when they differ from the CSR's query rows (0 = same)
 };
 
 // scratch memory lent by the caller (pointops2_set_workspace), thread-local

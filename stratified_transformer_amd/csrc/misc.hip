@@ -94,6 +94,7 @@ int pointops2_abi_version(void) { return 1; }
 void pointops2_set_table_rows(int L) { state().table_rows = L; }
 void pointops2_set_point_count(int N) { state().total_points = N; }
 void pointops2_set_batch_count(int b) { state().batch_count = b; }
+void pointops2_set_key_rows(int n) { state().key_rows = n; }
 void pointops2_set_csc(const int *csc_offsets, const int *csc_pair, const int *csc_query) {
     LaunchState &s = state();
     s.csc_offsets = csc_offsets;
@@ -139,7 +140,9 @@ size_t pointops2_csc_workspace_bytes(int N, int M) {
 void pointops2_csc_build(int N, int M, const int *index0_offsets, const int *index1,
                          int *csc_offsets, int *csc_pair, int *csc_query, void *workspace, size_t workspace_bytes) {
     if (N <= 0 || M <= 0) return;
-    if (workspace_bytes < pointops2_csc_workspace_bytes(N, M)) { set_error("pointops2_csc_build: workspace too small"); return; }
+    const int NK = state().key_rows > 0 ? state().key_rows : N;  // keys may outnumber the CSR's queries (sharded attention)
+    state().key_rows = 0;
+    if (workspace_bytes < pointops2_csc_workspace_bytes(NK > N ? NK : N, M)) { set_error("pointops2_csc_build: workspace too small"); return; }
     hipStream_t st = state().stream;
     char *ws = reinterpret_cast<char *>(workspace);
     const size_t seg = align256((size_t)M * sizeof(int));
@@ -151,9 +154,9 @@ void pointops2_csc_build(int N, int M, const int *index0_offsets, const int *ind
     hipLaunchKernelGGL(csr_expand_kernel, dim3(div_up(N, 4)), dim3(256), 0, st, N, index0_offsets, index0);
     hipLaunchKernelGGL(iota_kernel, dim3(div_up(M, 256)), dim3(256), 0, st, M, iota);
     // stable LSD radix sort: per key the pair ids stay ascending => deterministic summation order
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, index1, keys, (const int *)iota, csc_pair, M, 0, key_bits(N), st);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, index1, keys, (const int *)iota, csc_pair, M, 0, key_bits(NK), st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
-    hipLaunchKernelGGL(csc_finish_kernel, dim3(div_up(M, 256)), dim3(256), 0, st, N, M, keys, csc_pair, index0, csc_offsets, csc_query);
+    hipLaunchKernelGGL(csc_finish_kernel, dim3(div_up(M, 256)), dim3(256), 0, st, NK, M, keys, csc_pair, index0, csc_offsets, csc_query);
     check_launch();
 }
 

@@ -465,8 +465,9 @@ void dot_prod_with_idx_backward_cuda_launcher_v3(int N, int M, int h, int hdim, 
     hipStream_t st = state().stream;
     const LaunchState &ls = state();
     const int *co = ls.csc_offsets, *cp = ls.csc_pair;
+    const int NK = ls.key_rows > 0 ? ls.key_rows : N;
     // D=16, L<=80 with a CSC view: table gradients on the matrix cores (rpe_bwd_mfma.hip)
-    if (a2_bwd_mfma(N, h, hdim, L, grad_out, q, index_q_offsets, k, table_q, table_k, rel_idx, co, cp, grad_q, grad_k,
+    if (a2_bwd_mfma(N, NK, h, hdim, L, grad_out, q, index_q_offsets, k, table_q, table_k, rel_idx, co, cp, grad_q, grad_k,
                     grad_table_q, grad_table_k)) {
         check_launch();
         return;
@@ -479,8 +480,8 @@ void dot_prod_with_idx_backward_cuda_launcher_v3(int N, int M, int h, int hdim, 
             hipLaunchKernelGGL((a2_bwd_query_kernel<Dc, HGc, false>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \
                                lds_bytes, st, N, h, L, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx,  \
                                grad_q, grad_k, grad_table_q, grad_table_k);                                                 \
-            hipLaunchKernelGGL((a2_bwd_key_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256),        \
-                               lds_bytes, st, N, h, L, grad_out, k, co, cp, table_k, rel_idx, grad_k, grad_table_k);        \
+            hipLaunchKernelGGL((a2_bwd_key_kernel<Dc, HGc>), dim3(persistent_blocks(NK, ngroups), ngroups), dim3(256),       \
+                               lds_bytes, st, NK, h, L, grad_out, k, co, cp, table_k, rel_idx, grad_k, grad_table_k);       \
         })                                                                                                                  \
     } else {                                                                                                                \
         P2_LAUNCH_HG(D_, 4, {                                                                                               \
@@ -532,8 +533,9 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
     hipStream_t st = state().stream;
     const LaunchState &ls = state();
     const int *co = ls.csc_offsets, *cp = ls.csc_pair, *cq = ls.csc_query;
+    const int NK4 = ls.key_rows > 0 ? ls.key_rows : N;
     if (co && a4_bwd_mfma(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_table)) {
-        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(div_up(N, 4)), dim3(256), 0, st, N, h, co, cq, cp, attn, grad_out, grad_v);
+        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(div_up(NK4, 4)), dim3(256), 0, st, NK4, h, co, cq, cp, attn, grad_out, grad_v);
         check_launch();
         return;
     }
@@ -545,7 +547,7 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
             hipLaunchKernelGGL((a4_bwd_query_kernel<Dc, HGc, false>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \
                                lds_bytes, st, N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, \
                                grad_v, grad_table);                                                                         \
-            hipLaunchKernelGGL(key_accum_kernel<Dc>, dim3(div_up(N, 4)), dim3(256), 0, st, N, h, co, cq, cp, attn, grad_out, \
+            hipLaunchKernelGGL(key_accum_kernel<Dc>, dim3(div_up(NK4, 4)), dim3(256), 0, st, NK4, h, co, cq, cp, attn, grad_out, \
                                grad_v);                                                                                     \
         } else {                                                                                                            \
             hipLaunchKernelGGL((a4_bwd_query_kernel<Dc, HGc, true>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \

@@ -16,6 +16,7 @@
 // grad_q / grad_k / grad_attn are produced as in rpe.hip (table slices staged in LDS, no atomics).
 // Used for D = 16 and L <= 80 (all shipped configs) when a CSC view is set; otherwise rpe.hip's kernels run.
 #include "rpe_common.h"
+#include <cstdlib>
 
 namespace p2 {
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void a2_bwd_side_mfma_kernel(int N, int h, 
                                                                   const float *__restrict__ X, const int *__restrict__ offs,
                                                                   const int *__restrict__ pair_map, const float *__restrict__ table,
                                                                   const int *__restrict__ rel, float *__restrict__ grad_x,
-                                                                  float *__restrict__ grad_table) {
+                                                                  float *__restrict__ grad_table, int ablate) {
     constexpr int D = 16;
     using TG = TableGrad<HG, TA>;
     P2_WALK_PROLOGUE
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void a2_bwd_side_mfma_kernel(int N, int h, 
                     if (t < hgn) {
                         const float g = go[(size_t)m * h + h0 + t];
                         acc[t] = fma4(g, tsum<D>(T, L, t, r0, r1, r2, c), acc[t]);
-                        tg.add(hist, kk, t, c, rc, g);
+                        if (!(ablate & 1)) tg.add(hist, kk, t, c, rc, g);
                     }
                 }
             }
@@ -137,17 +138,17 @@ __global__ __launch_bounds__(256, 2) void a2_bwd_side_mfma_kernel(int N, int h, 
             }
         }
         if (++kk == 4) {
-            tg.mma_group(hist, xs, lane);
+            if (!(ablate & 2)) tg.mma_group(hist, xs, lane);
             kk = 0;
         }
     }
-    if (kk) tg.mma_group(hist, xs, lane);
+    if (kk && !(ablate & 2)) tg.mma_group(hist, xs, lane);
     __syncthreads();                 // every wave is done reading T
     zero_lds<D>(T, tsz);
     __syncthreads();
-    tg.merge(T, L, hgn, lane);
+    if (!(ablate & 4)) tg.merge(T, L, hgn, lane);
     __syncthreads();
-    flush_table<D>(T, grad_table, L, h, h0, hgn);
+    if (!(ablate & 8)) flush_table<D>(T, grad_table, L, h, h0, hgn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void a4_bwd_query_mfma_kernel(int N, int h,
                                                                    const int *__restrict__ offs, const int *__restrict__ idx1,
                                                                    const float *__restrict__ attn, const float *__restrict__ v,
                                                                    const float *__restrict__ table, const int *__restrict__ rel,
-                                                                   float *__restrict__ grad_attn, float *__restrict__ grad_table) {
+                                                                   float *__restrict__ grad_attn, float *__restrict__ grad_table, int ablate) {
     constexpr int D = 16;
     using TG = TableGrad<HG, TA>;
     P2_WALK_PROLOGUE
@@ -193,29 +194,35 @@ __global__ __launch_bounds__(256, 2) void a4_bwd_query_mfma_kernel(int N, int h,
                     float part = dot4(add4(tsum<D>(T, L, t, r0, r1, r2, c), v4), g4[t]);
                     float tot = xor_sum<1, LPG>(part);
                     if (c == t) keep = tot;
-                    if (valid) tg.add(hist, kk, t, c, rc, attn[(size_t)m * h + h0 + t]);
+                    if (valid && !(ablate & 1)) tg.add(hist, kk, t, c, rc, attn[(size_t)m * h + h0 + t]);
                 }
             }
             if (valid && c < hgn) grad_attn[(size_t)m * h + h0 + c] = keep;
         }
         if (++kk == 4) {
-            tg.mma_group(hist, xs, lane);
+            if (!(ablate & 2)) tg.mma_group(hist, xs, lane);
             kk = 0;
         }
     }
-    if (kk) tg.mma_group(hist, xs, lane);
+    if (kk && !(ablate & 2)) tg.mma_group(hist, xs, lane);
     __syncthreads();
     zero_lds<D>(T, tsz);
     __syncthreads();
-    tg.merge(T, L, hgn, lane);
+    if (!(ablate & 4)) tg.merge(T, L, hgn, lane);
     __syncthreads();
-    flush_table<D>(T, grad_table, L, h, h0, hgn);
+    if (!(ablate & 8)) flush_table<D>(T, grad_table, L, h, h0, hgn);
 }
 
 template <int HG, int TA>
 static size_t mfma_lds_bytes(int L) {
     using TG = TableGrad<HG, TA>;
     return ((size_t)HG * 3 * L * 16 + 4 * TG::HIST + 4 * TG::XS) * sizeof(float);
+}
+
+// diagnostic only (tools/bench_ops.py): P2_ABLATE bit 0 = no histogram adds, 1 = no MFMA, 2 = no merge, 3 = no flush
+static int ablate_mask() {
+    static const int v = getenv("P2_ABLATE") ? atoi(getenv("P2_ABLATE")) : 0;
+    return v;
 }
 
 static int mfma_blocks(int rows, int groups) {
@@ -226,7 +233,7 @@ static int mfma_blocks(int rows, int groups) {
 }
 
 template <int TA>
-static bool launch_a2(int N, int h, int L, const float *go, const float *q, const int *offs, const float *k,
+static bool launch_a2(int N, int NK, int h, int L, const float *go, const float *q, const int *offs, const float *k,
                       const float *table_q, const float *table_k, const int *rel, const int *co, const int *cp,
                       float *grad_q, float *grad_k, float *gtq, float *gtk, hipStream_t st) {
     // heads per workgroup: 3 at h >= 3 (75 KB LDS at L=64 -> two workgroups per CU)
@@ -237,9 +244,9 @@ static bool launch_a2(int N, int h, int L, const float *go, const float *q, cons
         allow_big_lds(a2_bwd_side_mfma_kernel<HG, TA, false>, lds);
         allow_big_lds(a2_bwd_side_mfma_kernel<HG, TA, true>, lds);
         hipLaunchKernelGGL((a2_bwd_side_mfma_kernel<HG, TA, false>), dim3(mfma_blocks(N, groups), groups), dim3(256), lds, st,
-                           N, h, L, go, q, offs, (const int *)nullptr, table_q, rel, grad_q, gtq);
-        hipLaunchKernelGGL((a2_bwd_side_mfma_kernel<HG, TA, true>), dim3(mfma_blocks(N, groups), groups), dim3(256), lds, st,
-                           N, h, L, go, k, co, cp, table_k, rel, grad_k, gtk);
+                           N, h, L, go, q, offs, (const int *)nullptr, table_q, rel, grad_q, gtq, ablate_mask());
+        hipLaunchKernelGGL((a2_bwd_side_mfma_kernel<HG, TA, true>), dim3(mfma_blocks(NK, groups), groups), dim3(256), lds, st,
+                           NK, h, L, go, k, co, cp, table_k, rel, grad_k, gtk, ablate_mask());
     };
     if (h >= 3) go_hg(std::integral_constant<int, 3>{});
     else if (h == 2) go_hg(std::integral_constant<int, 2>{});
@@ -256,7 +263,7 @@ static bool launch_a4(int N, int h, int L, const float *go, const int *offs, con
         const size_t lds = mfma_lds_bytes<HG, TA>(L);
         allow_big_lds(a4_bwd_query_mfma_kernel<HG, TA>, lds);
         hipLaunchKernelGGL((a4_bwd_query_mfma_kernel<HG, TA>), dim3(mfma_blocks(N, groups), groups), dim3(256), lds, st,
-                           N, h, L, go, offs, idx1, attn, v, table, rel, grad_attn, grad_table);
+                           N, h, L, go, offs, idx1, attn, v, table, rel, grad_attn, grad_table, ablate_mask());
     };
     if (h >= 3) go_hg(std::integral_constant<int, 3>{});
     else if (h == 2) go_hg(std::integral_constant<int, 2>{});
@@ -265,13 +272,13 @@ static bool launch_a4(int N, int h, int L, const float *go, const int *offs, con
 }
 
 // entry points used by rpe.hip; return false when the shape is outside this file's fast path
-bool a2_bwd_mfma(int N, int h, int hdim, int L, const float *go, const float *q, const int *offs, const float *k,
+bool a2_bwd_mfma(int N, int NK, int h, int hdim, int L, const float *go, const float *q, const int *offs, const float *k,
                  const float *table_q, const float *table_k, const int *rel, const int *co, const int *cp,
                  float *grad_q, float *grad_k, float *gtq, float *gtk) {
     if (hdim != 16 || co == nullptr || L < 1 || L > 80) return false;
     hipStream_t st = state().stream;
-    if (L <= 64) return launch_a2<4>(N, h, L, go, q, offs, k, table_q, table_k, rel, co, cp, grad_q, grad_k, gtq, gtk, st);
-    return launch_a2<5>(N, h, L, go, q, offs, k, table_q, table_k, rel, co, cp, grad_q, grad_k, gtq, gtk, st);
+    if (L <= 64) return launch_a2<4>(N, NK, h, L, go, q, offs, k, table_q, table_k, rel, co, cp, grad_q, grad_k, gtq, gtk, st);
+    return launch_a2<5>(N, NK, h, L, go, q, offs, k, table_q, table_k, rel, co, cp, grad_q, grad_k, gtq, gtk, st);
 }
 
 bool a4_bwd_mfma(int N, int h, int hdim, int L, const float *go, const int *offs, const int *idx1, const float *attn,

@@ -37,7 +37,7 @@ def _nmax(n_max):
 # key-major (CSC) view of a CSR pair list, shared by the backward kernels
 # ---------------------------------------------------------------------------------------------
 class _CSC:
-    __slots__ = ("offsets", "pair", "query", "keep")
+    __slots__ = ("offsets", "pair", "query", "keep", "n_keys")
 
     def __init__(self, offsets, pair, query, keep):
         self.offsets, self.pair, self.query, self.keep = offsets, pair, query, keep
@@ -61,22 +61,22 @@ def csc_of(index0_offsets, index1, n_keys):
         return hit
     M = int(index1.shape[0])
     N = int(index0_offsets.shape[0]) - 1
-    if N != n_keys:
-        return None  # the launchers carry a single N (as the reference's do): fall back to their atomic path
     dev = index1.device
     l = _lib.lib()
-    offsets = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    offsets = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
     pair = torch.empty(M, dtype=torch.int32, device=dev)
     query = torch.empty(M, dtype=torch.int32, device=dev)
     if M > 0:
-        nbytes = int(l.pointops2_csc_workspace_bytes(N, M))
+        nbytes = int(l.pointops2_csc_workspace_bytes(max(N, n_keys), M))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
+            l.pointops2_set_key_rows(int(n_keys))
             _lib.call("pointops2_csc_build", N, M, ptr(index0_offsets), ptr(index1), ptr(offsets), ptr(pair), ptr(query),
                       ptr(ws), nbytes, device=dev)
     else:
         offsets.zero_()
     csc = _CSC(offsets, pair, query, (index0_offsets, index1))
+    csc.n_keys = int(n_keys)
     _CSC_CACHE[key] = csc
     while len(_CSC_CACHE) > _CSC_CACHE_SIZE:
         _CSC_CACHE.popitem(last=False)
@@ -95,10 +95,13 @@ class _with_csc:
 
     def __enter__(self):
         if self.csc is not None:
-            _lib.lib().pointops2_set_csc(ptr(self.csc.offsets), ptr(self.csc.pair), ptr(self.csc.query))
+            l = _lib.lib()
+            l.pointops2_set_csc(ptr(self.csc.offsets), ptr(self.csc.pair), ptr(self.csc.query))
+            l.pointops2_set_key_rows(self.csc.n_keys)  # rows of k / v (may differ from the CSR's query rows)
 
     def __exit__(self, *exc):
         _lib.lib().pointops2_set_csc(None, None, None)
+        _lib.lib().pointops2_set_key_rows(0)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -277,7 +280,9 @@ class AttentionStep1_v2(Function):
         M = index1.shape[0]
         C = int(C_div_h * h)
         output = torch.empty((M, h), dtype=torch.float32, device=q.device)
-        pointops_cuda.attention_step1_forward_cuda_v2(N_k, M, h, C, _nmax(n_max), q, k, index0_offsets, index1, output)
+        # the launcher's N is the number of CSR rows (queries); the reference passes N_k, which is the same
+        # number in the model and would be wrong anywhere else (its kernel grid is one block per query)
+        pointops_cuda.attention_step1_forward_cuda_v2(int(index0_offsets.shape[0]) - 1, M, h, C, _nmax(n_max), q, k, index0_offsets, index1, output)
         ctx.N_q, ctx.N_k, ctx.C, ctx.n_max = N_q, N_k, C, n_max
         ctx.save_for_backward(q, k, index0_offsets, index1)
         return output
@@ -292,7 +297,7 @@ class AttentionStep1_v2(Function):
         grad_q = torch.empty((N_q, h, C // h), dtype=torch.float32, device=q.device)
         grad_k = _zeros((N_k, h, C // h), q)
         with _with_csc(csc_of(index0_offsets, index1, N_k)):
-            pointops_cuda.attention_step1_backward_cuda_v2(N_q, M, h, C, _nmax(ctx.n_max), grad_output, index0_offsets, index1, q, k, grad_q, grad_k)
+            pointops_cuda.attention_step1_backward_cuda_v2(int(index0_offsets.shape[0]) - 1, M, h, C, _nmax(ctx.n_max), grad_output, index0_offsets, index1, q, k, grad_q, grad_k)
         return grad_q, grad_k, None, None, None
 
 
@@ -488,8 +493,9 @@ class AttentionStep2WithRelPosValue_v2(Function):
         assert attn.is_contiguous() and v.is_contiguous() and index0_offsets.is_contiguous() and index1.is_contiguous() \
             and table.is_contiguous() and rel_idx.is_contiguous()
         M, h = attn.shape
-        N, h, hdim = v.shape
-        output = _zeros((N, h, hdim), v)  # queries beyond the CSR (none in the model) stay zero
+        N_v, h, hdim = v.shape
+        N = int(index0_offsets.shape[0]) - 1  # CSR rows = queries (== N_v in the model, :594-597)
+        output = torch.empty((N, h, hdim), dtype=torch.float32, device=v.device)
         pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, _nmax(n_max), attn, v, index0_offsets, index1, table, rel_idx, output)
         ctx.n_max = n_max
         ctx.save_for_backward(attn, v, index0_offsets, index1, table, rel_idx)
@@ -499,12 +505,13 @@ class AttentionStep2WithRelPosValue_v2(Function):
     def backward(ctx, grad_output):
         """:606-644 -> grad_attn, grad_v, None, None, None, grad_table, None (grad_output must be contiguous, :621)"""
         attn, v, index0_offsets, index1, table, rel_idx = ctx.saved_tensors
-        N, h, hdim = v.shape
+        N_v, h, hdim = v.shape
+        N = int(index0_offsets.shape[0]) - 1
         M, L = attn.shape[0], table.shape[0]
         assert grad_output.is_contiguous()
         grad_attn = torch.empty((M, h), dtype=torch.float32, device=v.device)
-        grad_v, grad_table = _zeros((N, h, hdim), v), _zeros((L, h, hdim, 3), v)
-        with _with_csc(csc_of(index0_offsets, index1, N)):
+        grad_v, grad_table = _zeros((N_v, h, hdim), v), _zeros((L, h, hdim, 3), v)
+        with _with_csc(csc_of(index0_offsets, index1, N_v)):
             pointops_cuda.attention_step2_with_rel_pos_value_backward_cuda_v2(N, M, h, hdim, _nmax(ctx.n_max), grad_output, index0_offsets, index1,
                                                                               attn, v, table, rel_idx, grad_attn, grad_v, grad_table)
         return grad_attn, grad_v, None, None, None, grad_table, None

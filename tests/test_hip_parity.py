@@ -431,3 +431,37 @@ def test_index_build_hip_matches_oracle_and_torch_path(n, nbatch, w, quant):
         s, l = ("small", "large") if par == 0 else ("small_shift", "large_shift")
         tb = index_build.build_block_index(xyz, parts[s], parts[l], dev(ds), w, quant, par == 1)
         assert torch.equal(tb.index_1, blk.index_1) and torch.equal(tb.rel_idx, blk.rel_idx) and torch.equal(tb.offsets, blk.offsets)
+
+
+def test_query_shard_ops_with_more_keys_than_queries(P):
+    """What a rank of a sharded scene runs: CSR rows = its own queries, k/v rows = all points.  The rows
+    of the sharded results equal the unsharded ones; key-side gradients sum over shards to the full ones."""
+    from stratified_transformer_amd import sharding
+    from stratified_transformer_amd.index_build import BlockIndex
+    p = window_problem(3000, seed=31, h=3, d=16)
+    block = BlockIndex(dev(p["index_0"]), dev(p["index_1"]), dev(p["offsets"]), None, dev(p["rel_idx"]), None)
+    k_full, v_full = dev(p["k"]), dev(p["v"])
+    tabs = [dev(p[x]) for x in ("table_q", "table_k", "table_v")]
+
+    def run(q, k, v, tq, tk, tv, offs, i1, rel, go):
+        q, k, v, tq, tk, tv = (x.clone().requires_grad_(True) for x in (q, k, v, tq, tk, tv))
+        a1 = P.attention_step1_v2(q, k, i1, offs, 0)
+        a2 = P.dot_prod_with_idx_v3(q, offs, 0, k, i1, tq, tk, rel)
+        out = P.attention_step2_with_rel_pos_value_v2(P.segment_softmax(a1 + a2, offs), v, offs, 0, i1, tv, rel)
+        out.backward(go)
+        return out.detach(), [x.grad for x in (q, k, v, tq, tk, tv)]
+
+    full_out, full_g = run(dev(p["q"]), k_full, v_full, *tabs, block.offsets, block.index_1, block.rel_idx, dev(p["go_rows"]))
+    world = 3
+    acc = [torch.zeros_like(g) for g in full_g[1:]]
+    bounds = None
+    for rank in range(world):
+        shard, bounds = sharding.make_shard(block, rank, world, bounds)
+        out, g = run(dev(p["q"][shard.lo:shard.hi]), k_full, v_full, *tabs, shard.offsets, shard.index_1, shard.rel_idx,
+                     dev(p["go_rows"][shard.lo:shard.hi]))
+        np.testing.assert_allclose(_np(out), _np(full_out)[shard.lo:shard.hi], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(_np(g[0]), _np(full_g[0])[shard.lo:shard.hi], rtol=1e-5, atol=1e-5)
+        for a, x in zip(acc, g[1:]):
+            a += x
+    for a, f in zip(acc, full_g[1:]):
+        np.testing.assert_allclose(_np(a), _np(f), rtol=2e-4, atol=2e-4)

@@ -144,15 +144,133 @@ __global__ void fps_morton_kernel(int N, int b, const float *__restrict__ xyz, c
 
 // sorted-order point records: (x, y, z, running min-dist) as one 16-byte load, plus the 31-bit tie rank
 __global__ void fps_gather_kernel(int N, int b, int Bref, int log2B, const float *__restrict__ xyz, const int *__restrict__ offset,
-                                  const int *__restrict__ order, float4 *__restrict__ pts, unsigned *__restrict__ rank) {
+                                  const int *__restrict__ order, float4 *__restrict__ pts, unsigned *__restrict__ rank,
+                                  int *__restrict__ inv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int o = order[i];
+    inv[o] = i;
     pts[i] = make_float4(xyz[(size_t)o * 3 + 0], xyz[(size_t)o * 3 + 1], xyz[(size_t)o * 3 + 2], 1e10f);  // pointops.py:26
     int bid = 0;
     while (bid < b - 1 && i >= offset[bid]) bid++;
     const int start_n = bid == 0 ? 0 : offset[bid - 1];
     rank[i] = (unsigned)key_of(0.f, o - start_n, Bref, log2B);
+}
+
+// ---- identity-prefix verification ----------------------------------------------------------------
+// A cloud that is itself the output of an earlier FPS (every stage after the first: TransitionDown keeps
+// the samples in selection order, stratified_transformer.py:103-104) is sampled again as 0, 1, 2, ...:
+// the arg-max property of a prefix is inherited by any subset that contains it.  Exact ties aside, the
+// m dependent steps collapse into a CHECK that is embarrassingly parallel: sample j is right iff no point
+// has a larger key than point j after the first j samples.  The check is exact (same fma chain, same tie
+// ranks); where it fails (first step of an unordered cloud, or a genuine tie) the sequential sampler
+// takes over from the verified prefix.
+constexpr int VER_T = 256;
+
+// thresholds: T[j] = key of point j after samples 0..j-1, for j in [jlo, jhi)
+__global__ __launch_bounds__(VER_T) void fps_verify_threshold_kernel(int Bref, int log2B, int jlo, const float *__restrict__ xyz,
+                                                                     const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                                     const int *__restrict__ first_bad, unsigned long long *__restrict__ T) {
+    const int bid = blockIdx.y;
+    const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
+    const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
+    const int m = min(end_m - start_m, end_n - start_n);  // the identity prefix cannot be longer than the cloud
+    if (first_bad[bid] < jlo) return;
+    const int j = jlo + blockIdx.x * VER_T + threadIdx.x;
+    __shared__ float sx[VER_T], sy[VER_T], sz[VER_T];
+    const int jmax = min(jlo + (int)(blockIdx.x + 1) * VER_T, m);  // tiles of samples needed by this block: i < jmax
+    if (jlo + (int)blockIdx.x * VER_T >= m) return;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (j < m) { px = xyz[(size_t)(start_n + j) * 3]; py = xyz[(size_t)(start_n + j) * 3 + 1]; pz = xyz[(size_t)(start_n + j) * 3 + 2]; }
+    float D = 1e10f;
+    for (int i0 = 0; i0 < jmax; i0 += VER_T) {
+        __syncthreads();
+        const int i = i0 + threadIdx.x;
+        if (i < jmax) { sx[threadIdx.x] = xyz[(size_t)(start_n + i) * 3]; sy[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 1]; sz[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 2]; }
+        __syncthreads();
+        const int lim = min(VER_T, j - i0);  // samples i < j
+        for (int t = 0; t < lim; t++) D = fminf(D, sqd(px - sx[t], py - sy[t], pz - sz[t]));
+    }
+    if (j < m) T[start_n + j] = ((unsigned long long)__float_as_uint(D) << 32) | (unsigned)key_of(0.f, j, Bref, log2B);
+}
+
+// scan: every point x checks key_x(j) <= T[j] for j in [jlo, jhi); first violation -> first_bad (atomic min)
+__global__ __launch_bounds__(VER_T) void fps_verify_scan_kernel(int Bref, int log2B, int jlo, int jhi_cap, const float *__restrict__ xyz,
+                                                                const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                                const unsigned long long *__restrict__ T, int *__restrict__ first_bad) {
+    const int bid = blockIdx.y;
+    const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
+    const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
+    const int n = end_n - start_n;
+    const int m = min(min(end_m - start_m, n), jhi_cap);
+    if (first_bad[bid] < jlo || (int)blockIdx.x * VER_T >= n) return;
+    const int x = blockIdx.x * VER_T + threadIdx.x;
+    __shared__ float sx[VER_T], sy[VER_T], sz[VER_T];
+    __shared__ unsigned long long sT[VER_T];
+    __shared__ int s_fb;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    const bool live = x < n;
+    if (live) { px = xyz[(size_t)(start_n + x) * 3]; py = xyz[(size_t)(start_n + x) * 3 + 1]; pz = xyz[(size_t)(start_n + x) * 3 + 2]; }
+    const unsigned rk = (unsigned)key_of(0.f, x, Bref, log2B);
+    float D = 1e10f;
+    int bad = 0x7fffffff;
+    // step j uses samples 0..j-1: tile t holds samples i0..i0+255 and thresholds of steps i0+1..i0+256
+    for (int i0 = 0; i0 < m - 1; i0 += VER_T) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_fb = *reinterpret_cast<volatile int *>(first_bad + bid);
+        __syncthreads();
+        if (i0 > s_fb) break;  // block-uniform: an earlier step already failed somewhere
+        const int i = i0 + threadIdx.x;
+        if (i < m - 1) {
+            sx[threadIdx.x] = xyz[(size_t)(start_n + i) * 3]; sy[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 1]; sz[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 2];
+            sT[threadIdx.x] = (i + 1 >= jlo) ? T[start_n + i + 1] : ~0ull;
+        }
+        __syncthreads();
+        const int lim = min(VER_T, m - 1 - i0);
+        if (live && bad == 0x7fffffff) {
+            for (int t = 0; t < lim; t++) {
+                D = fminf(D, sqd(px - sx[t], py - sy[t], pz - sz[t]));
+                const unsigned long long key = ((unsigned long long)__float_as_uint(D) << 32) | rk;
+                if (key > sT[t]) { bad = i0 + t + 1; break; }
+            }
+        }
+    }
+    if (bad != 0x7fffffff) atomicMin(first_bad + bid, bad);
+}
+
+__global__ void fps_verify_init_kernel(int b, const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ first_bad) {
+    const int bid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bid >= b) return;
+    const int n = offset[bid] - (bid == 0 ? 0 : offset[bid - 1]);
+    const int m = new_offset[bid] - (bid == 0 ? 0 : new_offset[bid - 1]);
+    first_bad[bid] = max(min(m, n), 0);  // = number of samples that are verified to be 0,1,2,... (lowered by the scans)
+}
+
+// min-dist field after the verified prefix (samples 0..v-2 applied), written in sampler (Morton) order;
+// only where the verified prefix is longer than what the kept sampler state already covers
+__global__ __launch_bounds__(VER_T) void fps_rebuild_kernel(const float *__restrict__ xyz, const int *__restrict__ offset,
+                                                            const int *__restrict__ prev_offset, const int *__restrict__ first_bad,
+                                                            const int *__restrict__ inv, float4 *__restrict__ pts) {
+    const int bid = blockIdx.y;
+    const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
+    const int n = end_n - start_n;
+    const int prev = prev_offset ? prev_offset[bid] - (bid == 0 ? 0 : prev_offset[bid - 1]) : 0;
+    const int v = first_bad[bid];
+    if (v <= prev || v <= 1 || (int)blockIdx.x * VER_T >= n) return;
+    const int x = blockIdx.x * VER_T + threadIdx.x;
+    __shared__ float sx[VER_T], sy[VER_T], sz[VER_T];
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (x < n) { px = xyz[(size_t)(start_n + x) * 3]; py = xyz[(size_t)(start_n + x) * 3 + 1]; pz = xyz[(size_t)(start_n + x) * 3 + 2]; }
+    float D = 1e10f;
+    for (int i0 = 0; i0 < v - 1; i0 += VER_T) {
+        __syncthreads();
+        const int i = i0 + threadIdx.x;
+        if (i < v - 1) { sx[threadIdx.x] = xyz[(size_t)(start_n + i) * 3]; sy[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 1]; sz[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 2]; }
+        __syncthreads();
+        const int lim = min(VER_T, v - 1 - i0);
+        for (int t = 0; t < lim; t++) D = fminf(D, sqd(px - sx[t], py - sy[t], pz - sz[t]));
+    }
+    if (x < n) reinterpret_cast<float *>(pts + inv[start_n + x])[3] = D;
 }
 
 // ---- sampling --------------------------------------------------------------------------------
@@ -218,7 +336,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
                                                              const int *__restrict__ offset, const int *__restrict__ new_offset,
                                                              float4 *__restrict__ pts, const unsigned *__restrict__ rank,
                                                              const int *__restrict__ prev_idx, const int *__restrict__ prev_offset,
-                                                             int *__restrict__ idx, unsigned long long *__restrict__ dbg = nullptr) {
+                                                             const int *__restrict__ verified, int *__restrict__ idx,
+                                                             unsigned long long *__restrict__ dbg = nullptr) {
     constexpr int NT = NW * 64;
     unsigned long long c_test = 0, c_red = 0, c_bar = 0, c_fin = 0, n_upd = 0, t_a = 0, t_b = 0;
     unsigned long long rt0 = 0, ct0 = 0;
@@ -242,6 +361,14 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
         const int ps = bid == 0 ? 0 : prev_offset[bid - 1], pe = prev_offset[bid];
         done = min(pe - ps, end_m - start_m);
         for (int t = tid; t < done; t += NT) idx[start_m + t] = prev_idx[ps + t];
+    }
+    // samples verified to be the identity prefix 0,1,2,... (fps_verify_*); the min-dist field was rebuilt for them
+    if (verified) {
+        const int v = min(verified[bid], end_m - start_m);
+        if (v > done) {
+            for (int t = tid; t < v; t += NT) idx[start_m + t] = start_n + t;
+            done = v;
+        }
     }
     if (start_m + done >= end_m) return;
 
@@ -505,6 +632,9 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     unsigned long long *keys_in = (unsigned long long *)p; p += f8;
     unsigned long long *keys_out = (unsigned long long *)p; p += f8;
     float *bbox = (float *)p; p += al((size_t)b * 6 * 4);
+    int *inv = (int *)p; p += f4;                                   // original index -> sampler order (persistent)
+    unsigned long long *thr = (unsigned long long *)p; p += f8;    // verification thresholds
+    int *first_bad = (int *)p; p += al((size_t)b * 4);
     void *cub_tmp = p;
     size_t cub_bytes = w.bytes - (size_t)(p - reinterpret_cast<char *>(w.ptr));
     FpsResume rs = fps_resume();
@@ -515,7 +645,20 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
         hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys_in, keys_out, (const int *)vals_in, sorig, N_total, 0,
                                                           32 + bits_for(b), st);
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return true; }
-        hipLaunchKernelGGL(fps_gather_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, b, Bref, log2B, xyz, offset, sorig, pts, rank);
+        hipLaunchKernelGGL(fps_gather_kernel, dim3(div_up(N_total, 256)), dim3(256), 0, st, N_total, b, Bref, log2B, xyz, offset, sorig, pts, rank, inv);
+    }
+    // identity-prefix verification (exact; see above): a cheap probe of the first 64 steps, then everything
+    static const bool no_verify = getenv("P2_FPS_NO_VERIFY") != nullptr;
+    const int *verified = nullptr;
+    if (!no_verify) {
+        const int gx = div_up(n, VER_T);
+        hipLaunchKernelGGL(fps_verify_init_kernel, dim3(div_up(b, 64)), dim3(64), 0, st, b, offset, new_offset, first_bad);
+        hipLaunchKernelGGL(fps_verify_threshold_kernel, dim3(1, b), dim3(VER_T), 0, st, Bref, log2B, 1, xyz, offset, new_offset, first_bad, thr);
+        hipLaunchKernelGGL(fps_verify_scan_kernel, dim3(gx, b), dim3(VER_T), 0, st, Bref, log2B, 1, 64, xyz, offset, new_offset, thr, first_bad);
+        hipLaunchKernelGGL(fps_verify_threshold_kernel, dim3(gx, b), dim3(VER_T), 0, st, Bref, log2B, 64, xyz, offset, new_offset, first_bad, thr);
+        hipLaunchKernelGGL(fps_verify_scan_kernel, dim3(gx, b), dim3(VER_T), 0, st, Bref, log2B, 64, 0x7fffffff, xyz, offset, new_offset, thr, first_bad);
+        hipLaunchKernelGGL(fps_rebuild_kernel, dim3(gx, b), dim3(VER_T), 0, st, xyz, offset, rs.prev_offset, first_bad, inv, pts);
+        verified = first_bad;
     }
     const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);
     const int nbuckets = div_up(n, BSZ);
@@ -524,7 +667,7 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     const int per_lane = div_up(nbuckets, NWsel * 64);
 #define P2_FPS_LAUNCH(NBL_, NW_, STAMP_, DBG_)                                                                              \
     hipLaunchKernelGGL((fps_bucket_kernel<NBL_, NW_, STAMP_>), dim3(b), dim3(NW_ * 64), 0, st, Bref, log2B, BSZ, xyz, offset, \
-                       new_offset, pts, rank, rs.prev_idx, rs.prev_offset, idx, DBG_)
+                       new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, DBG_)
     if (getenv("P2_FPS_STAMPS") && nbuckets > 1024) {  // diagnostic only: synchronous, prints phase shares to stderr
         unsigned long long *dbg = nullptr, host[16 * 8];
         (void)hipMalloc(&dbg, sizeof(host) * b);
@@ -563,7 +706,7 @@ void pointops2_set_workspace(void *ptr, size_t bytes) {
 
 size_t pointops2_fps_workspace_bytes(int b, int N) {
     if (b <= 0 || N <= 0) return 0;
-    return al((size_t)N * 16) + 3 * al((size_t)N * 4) + 2 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al(fps_cub_bytes(b, N));
+    return al((size_t)N * 16) + 4 * al((size_t)N * 4) + 3 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al((size_t)b * 4) + al(fps_cub_bytes(b, N));
 }
 
 void pointops2_set_fps_resume(const int *prev_idx, const int *prev_offset) {

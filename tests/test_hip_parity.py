@@ -465,3 +465,30 @@ def test_query_shard_ops_with_more_keys_than_queries(P):
             a += x
     for a, f in zip(acc, full_g[1:]):
         np.testing.assert_allclose(_np(a), _np(f), rtol=2e-4, atol=2e-4)
+
+
+def test_fps_of_an_fps_ordered_cloud_is_verified_in_parallel(P):
+    """Stage s+1 samples the cloud stage s produced in selection order: the answer is 0,1,2,... and the
+    parallel verification must find exactly what the sequential sampler (and the oracle) finds — also when
+    the order is broken part-way, with batches, with resume, and with exact ties."""
+    from stratified_transformer_amd import scene
+    xyz = scene.make_room(12000, 9)
+    order = ref.furthestsampling(xyz, np.array([12000], np.int32), np.array([3001], np.int32))
+    sub = np.ascontiguousarray(xyz[order])                                   # FPS-ordered cloud of 3001 points
+    broken = sub.copy()
+    broken[[700, 1900]] = broken[[1900, 700]]                                # order wrong from step 700 on
+    two = np.concatenate([sub, broken])                                      # batch of both
+    for cloud, offset, new_offset in ((sub, [3001], [376]), (sub, [3001], [751]), (sub, [3001], [3001]),
+                                      (broken, [3001], [1200]), (two, [3001, 6002], [751, 1502])):
+        P.clear_caches()
+        got = _fps(P, cloud, offset, new_offset)
+        want = ref.furthestsampling(cloud, np.asarray(offset, np.int32), np.asarray(new_offset, np.int32))
+        assert np.array_equal(got, want), (offset, new_offset)
+    assert np.array_equal(_fps(P, sub, [3001], [751]), np.arange(751))        # the identity prefix indeed
+    # resume across the verified / sequential boundary
+    P.clear_caches()
+    x, off = dev(broken), dev(np.array([3001], np.int32))
+    a = _np(P.furthestsampling(x, off, dev(np.array([376], np.int32))))
+    b = _np(P.furthestsampling(x, off, dev(np.array([1500], np.int32))))
+    full = ref.furthestsampling(broken, np.array([3001], np.int32), np.array([1500], np.int32))
+    assert np.array_equal(b, full) and np.array_equal(a, full[:376])

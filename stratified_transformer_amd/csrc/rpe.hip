@@ -17,24 +17,30 @@
 //    9216-float table.  Key-side gradients are produced by key through the CSC view
 //    (pointops2_set_csc); without it the by-query kernel falls back to global atomics.
 #include "rpe_common.h"
+#include <cstdlib>
 
 namespace p2 {
 
 // ------------------------------------------------------------------------------------------------
 // A2 forward: out[m,hh] = sum_i q[query,hh,i]*Tq(m,hh,i) + k[idx_k[m],hh,i]*Tk(m,hh,i)
 // ------------------------------------------------------------------------------------------------
+// The per-query loops are latency-bound (index -> key row -> LDS table rows is a dependent chain and a
+// segment is only ~3 passes long): time scales with 1/(waves per CU) (A2 forward, stage 0: 674 / 371 / 227 us
+// at 4 / 8 / 16 waves per CU).  So workgroups are as large as the register budget allows: the LDS table
+// images are shared by all waves of a workgroup, two (A2: 72 KB) or four (A4: 36 KB) of them per CU.
 template <int D, int HG>
-__global__ __launch_bounds__(256) void a2_fwd_kernel(int N, int h, int L, const float *__restrict__ q,
-                                                     const int *__restrict__ offs, const float *__restrict__ k,
-                                                     const int *__restrict__ idx_k, const float *__restrict__ table_q,
-                                                     const float *__restrict__ table_k, const int *__restrict__ rel,
-                                                     float *__restrict__ out) {
+__global__ __launch_bounds__(768, 6) void a2_fwd_kernel(int N, int h, int L, const float *__restrict__ q,
+                                                        const int *__restrict__ offs, const float *__restrict__ k,
+                                                        const int *__restrict__ idx_k, const float *__restrict__ table_q,
+                                                        const float *__restrict__ table_k, const int *__restrict__ rel,
+                                                        float *__restrict__ out) {
     P2_WALK_PROLOGUE
     float *Tq = lds, *Tk = lds + tsz;
     stage_table<D>(Tq, table_q, L, h, h0, hgn);
     stage_table<D>(Tk, table_k, L, h, h0, hgn);
     __syncthreads();
-    for (int qi = blockIdx.x * 4 + wave; qi < N; qi += gridDim.x * 4) {
+    const int wpb = blockDim.x >> 6;
+    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
         float4 q4[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++)
@@ -180,15 +186,16 @@ __global__ __launch_bounds__(256) void a2_bwd_key_kernel(int N, int h, int L, co
 // A4 forward: out[q,hh,:] = sum_m attn[m,hh] * (v[idx1[m],hh,:] + Tv(m,hh,:))
 // ------------------------------------------------------------------------------------------------
 template <int D, int HG>
-__global__ __launch_bounds__(256) void a4_fwd_kernel(int N, int h, int L, const float *__restrict__ attn,
-                                                     const float *__restrict__ v, const int *__restrict__ offs,
-                                                     const int *__restrict__ idx1, const float *__restrict__ table,
-                                                     const int *__restrict__ rel, float *__restrict__ out) {
+__global__ __launch_bounds__(512, 8) void a4_fwd_kernel(int N, int h, int L, const float *__restrict__ attn,
+                                                        const float *__restrict__ v, const int *__restrict__ offs,
+                                                        const int *__restrict__ idx1, const float *__restrict__ table,
+                                                        const int *__restrict__ rel, float *__restrict__ out) {
     P2_WALK_PROLOGUE
     float *Tv = lds;
     stage_table<D>(Tv, table, L, h, h0, hgn);
     __syncthreads();
-    for (int qi = blockIdx.x * 4 + wave; qi < N; qi += gridDim.x * 4) {
+    const int wpb = blockDim.x >> 6;
+    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
         float4 acc[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++) acc[t] = make_float4(0, 0, 0, 0);
@@ -395,10 +402,11 @@ static int table_rows_or_error() {
     return L;
 }
 
-static int persistent_blocks(int rows, int head_groups) {
-    int want = div_up(rows, 4);
-    int cap = kNumCU * 2;  // 72 KB LDS => two workgroups per CU
-    if (head_groups > 1) cap = max(kNumCU * 2 / head_groups, kNumCU / 2);
+// waves_per_block: rows a workgroup handles at a time; per_cu: resident workgroups per CU (LDS / register budget)
+static int persistent_blocks(int rows, int head_groups, int waves_per_block = 4, int per_cu = 2) {
+    int want = div_up(rows, waves_per_block);
+    int cap = kNumCU * per_cu;
+    if (head_groups > 1) cap = max(kNumCU * per_cu / head_groups, kNumCU / 2);
     return min(want, cap);
 }
 
@@ -441,12 +449,12 @@ void dot_prod_with_idx_forward_cuda_launcher_v3(int N, int M, int h, int hdim, i
     hipStream_t st = state().stream;
     if (hdim == 16) P2_LAUNCH_HG(16, 2, {
         allow_big_lds(a2_fwd_kernel<Dc, HGc>, lds_bytes);
-        hipLaunchKernelGGL((a2_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), lds_bytes, st,
+        hipLaunchKernelGGL((a2_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 12, 2), ngroups), dim3(768), lds_bytes, st,
                            N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output);
     })
     else if (hdim == 32) P2_LAUNCH_HG(32, 2, {
         allow_big_lds(a2_fwd_kernel<Dc, HGc>, lds_bytes);
-        hipLaunchKernelGGL((a2_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), lds_bytes, st,
+        hipLaunchKernelGGL((a2_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 12, 2), ngroups), dim3(768), lds_bytes, st,
                            N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output);
     })
     else { set_error("d != 16 and d != 32"); return; }
@@ -509,12 +517,12 @@ void attention_step2_with_rel_pos_value_forward_cuda_launcher_v2(int N, int M, i
     hipStream_t st = state().stream;
     if (hdim == 16) P2_LAUNCH_HG(16, 1, {
         allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
-        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), lds_bytes, st,
+        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 8, 4), ngroups), dim3(512), lds_bytes, st,
                            N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output);
     })
     else if (hdim == 32) P2_LAUNCH_HG(32, 1, {
         allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
-        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), lds_bytes, st,
+        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 8, 4), ngroups), dim3(512), lds_bytes, st,
                            N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output);
     })
     else { set_error("d != 16 and d != 32"); return; }

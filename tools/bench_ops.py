@@ -16,7 +16,12 @@ def timeit(fn, n=10):
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     cfg = pipeline.s3dis_config(); st = cfg.stages[0]
-    xyz = torch.from_numpy(scene.make_room(N, 0)).cuda()
+    xyz_np = scene.make_room(N, 0)
+    if os.environ.get('SORTED'):
+        c = np.floor(xyz_np / 0.16).astype(np.int64)
+        key = (c[:, 2] * 64 + c[:, 1]) * 64 + c[:, 0]
+        xyz_np = np.ascontiguousarray(xyz_np[np.argsort(key, kind='stable')])
+    xyz = torch.from_numpy(xyz_np).cuda()
     off = torch.tensor([N], dtype=torch.int32, device='cuda')
     ds = P.furthestsampling(xyz, off, torch.tensor([N // 8 + 1], dtype=torch.int32, device='cuda'))
     even, odd, _ = index_build.stage_index_hip(xyz, off, st.window_size, st.quant_size, ds)

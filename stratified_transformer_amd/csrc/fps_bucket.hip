@@ -40,24 +40,6 @@ constexpr int FPS_MAX_BUCKETS = 2048;
 __device__ __forceinline__ float sqd(float dx, float dy, float dz) {
     return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
 }
-// wave-wide unsigned max with DPP row operations (6 VALU + 1 readlane; a __shfl_xor butterfly costs 6
-// dependent ds_bpermute round trips, and the 64-bit key would double that)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_step(unsigned v) {
-    // old = 0 (identity of unsigned max) + bound_ctrl: rows masked off / lanes without a source read 0, which
-    // lets the DPP combiner fold the move into v_max_u32_dpp (one instruction per step)
-    const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
-    return v > t ? v : t;
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-    v = dpp_step<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v = dpp_step<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v = dpp_step<0x141, 0xF>(v);  // row_half_mirror
-    v = dpp_step<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row max
-    v = dpp_step<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
-    v = dpp_step<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3: lane 63 holds the wave max
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
 // maximum over lanes 0..15 only (values in the first row): four row steps, result in every lane of row 0
 __device__ __forceinline__ unsigned row0_max_u32(unsigned v) {
     v = dpp_step<0xB1, 0xF>(v);

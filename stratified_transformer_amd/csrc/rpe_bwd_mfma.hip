@@ -1,19 +1,33 @@
-// Backward of A2 / A4 with the table gradients on the matrix cores, gfx950.
+// Backward of A2 / A4 for D = 16 with a key-major (CSC) view of the pair list, gfx950: no global atomics
+// except the final table flush, table gradients on the matrix cores.
 //
-// The gradient of a relative-position table is
-//     grad_table[r, hh, i, ax] = sum over pairs m with rel[m, ax] == r of  w[m, hh] * X[row(m), hh, i]
-// (w = grad_out and X = q or k for the bias A2; w = attn and X = grad_out for the value term A4).
-// The reference adds every (pair, i, ax) term with a global atomic into a 9216-float table
+// The walk over a row's pairs (pair -> rel index -> LDS table rows) is a chain of dependent accesses and a
+// row is only ~3 wave passes long, so these kernels are latency-bound: time goes with 1/(waves per CU)
+// (rpe.hip, A2 forward).  A kernel that keeps a table-gradient slice in MFMA accumulators per wave
+// (144 registers) runs at 8 waves per CU and spent 75 % of its time in the walk it shares with the row
+// gradients.  So the work is split by what limits it:
+//
+//   rows_table_sum_kernel   grad_q / grad_k rows:  sum over the row's pairs of w * T(rel)     32 waves / CU
+//   a4_bwd_attn_kernel      grad_attn per pair:    <T(rel) + v[key], grad_out[query]>          32 waves / CU
+//   table_grad_kernel       all three table gradients (below)                                  24 waves / CU
+//
+// Table gradient.  grad_table[r, hh, i, ax] = sum over pairs m with rel[m, ax] == r of w[m, hh] * X[row(m), hh, i]
+// (w = grad_out, X = q or k for the bias A2; w = attn, X = grad_out for the value term A4).  The reference
+// adds every (pair, i, ax) term with a global atomic into a 9216-float table
 // (relative_pos_encoding_cuda_kernel_v2.cu:327-332, :478-480).  Here the sum is factored per row:
-//     H_row[ax][r]   = sum of w over the row's pairs with rel == r        (a 3 x L histogram)
-//     grad_table    += H_row^T (3L x 1)  x  X_row (1 x D)                 (an outer product)
-// so per pair only 3 LDS adds remain (one lane per axis), and the outer products of four consecutive
-// rows are one K=4 step of v_mfma_f32_16x16x4_f32 per 16-bin tile: D[bin, i] += A[bin, row] * B[row, i].
+//     H_row[ax][r]   = sum of w over the row's pairs with rel == r        (a 3 x L histogram per head)
+//     grad_table    += H_row^T (3L x 1)  x  X_row (1 x 16)                (an outer product)
+// A workgroup of 12 waves takes 12 rows at a time: every wave builds the histogram of one row in LDS
+// (3 integer LDS adds per pair and head), then - after a barrier - the 12 outer products are three K=4
+// steps of v_mfma_f32_16x16x4_f32 per 16-bin tile, D[bin, i] += A[bin, row] * B[row, i], and the tiles of
+// the table slice (HG heads x 3 axes x L/16) are dealt out over the 12 waves: 3 tiles = 12 accumulator
+// registers per wave instead of the whole slice.  Nothing has to be merged at the end; every wave flushes
+// its own tiles with one global atomic per table entry.  f32 MFMA is exact fp32 (fma chain).
 //
 // The histogram is kept in 32-bit FIXED POINT with a per-row power-of-two scale: on gfx950 an LDS float
 // atomic (ds_add_f32) retires ~1 lane per 3 cycles for the whole CU (192 cycles per wave instruction,
 // tools/ubench/lds_atomic.hip), an LDS integer atomic (ds_add_u32) runs at LDS write speed (~9-20 cycles per
-// wave instruction) - 10-40x faster, and integer sums do not depend on the order of the adds.  Per row:
+// wave instruction), and integer sums do not depend on the order of the adds.  Per row:
 //     E, n        max|w| < 2^E over the row's pairs, n pairs          (one extra sweep over w)
 //     S           = 30 - bits(n) - E, so that |sum of any bin| * 2^S < 2^30
 //     hist       += rne(w * 2^S)                                      (ds_add_u32)
@@ -21,11 +35,7 @@
 // Each term is rounded to max|w| * 2^-(29 - bits(n)), i.e. at n <= 64 pairs finer than the fp32 epsilon of the
 // row's largest weight - the same size as the rounding of an fp32 running sum, without its order dependence.
 // A row whose weights contain Inf/NaN poisons its tiles with NaN (the reference would propagate them too).
-// Each wave keeps its whole table-gradient slice (HG heads x 3L x 16, 144 registers at L=64) in MFMA
-// accumulators for the entire launch; the workgroup's four slices are merged in LDS once at the end and
-// flushed with one global atomic per table entry and workgroup.  f32 MFMA is exact fp32 (fma chain).
 //
-// grad_q / grad_k / grad_attn are produced as in rpe.hip (table slices staged in LDS, no atomics).
 // Used for D = 16 and L <= 80 (all shipped configs) when a CSC view is set; otherwise rpe.hip's kernels run.
 #include "rpe_common.h"
 #include <cstdlib>
@@ -34,142 +44,36 @@ namespace p2 {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int HG, int TA>
-struct TableGrad {
-    static constexpr int LP = TA * 16;                 // padded bins per axis
-    static constexpr int ROW = HG * 3 * LP + 16;       // floats per k-row of the per-wave histogram (+16: the four
-                                                       // k-rows read by one ds_read land on different banks)
-    static constexpr int HIST = 4 * ROW;               // floats per wave
-    static constexpr int XS = 4 * HG * 16;             // floats per wave: X rows of the current group
-    f32x4 acc[HG][3 * TA];
-
-    __device__ __forceinline__ void init(float *hist, float *xs, int lane) {
-#pragma unroll
-        for (int t = 0; t < HG; t++)
-#pragma unroll
-            for (int i = 0; i < 3 * TA; i++) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int x = lane; x < HIST; x += 64) hist[x] = 0.f;
-        for (int x = lane; x < XS; x += 64) xs[x] = 0.f;
-    }
-    // fixed-point scale of a row: maxbits = bit pattern of max|w| over its n pairs
-    struct Scale {
-        float mul, inv;
-    };
-    static __device__ __forceinline__ Scale row_scale(unsigned maxbits, int n) {
-        Scale sc;
-        if (maxbits >= 0x7f800000u) {  // Inf / NaN among the weights
-            sc.mul = 0.f;
-            sc.inv = __uint_as_float(0x7fc00000u);
-            return sc;
-        }
-        const int E = (int)(maxbits >> 23) - 126;   // max|w| < 2^E
-        const int bits_n = 32 - __clz(max(n, 1));   // n < 2^bits_n
-        const int S = max(-126, min(126, 30 - bits_n - E));
-        sc.mul = __uint_as_float((unsigned)(S + 127) << 23);
-        sc.inv = __uint_as_float((unsigned)(127 - S) << 23);
-        return sc;
-    }
-    // lane c (< 3) of a pair's lane group owns axis c
-    __device__ __forceinline__ void add(float *hist, int kk, int t, int c, int r, float w, float mul) {
-        if (c < 3) atomicAdd(reinterpret_cast<int *>(&hist[kk * ROW + (t * 3 + c) * LP + r]), __float2int_rn(w * mul));
-    }
-    __device__ __forceinline__ void put_x(float *xs, int kk, int t, int c, float4 x4, float inv) {
-        *reinterpret_cast<float4 *>(&xs[(kk * HG + t) * 16 + 4 * c]) = make_float4(x4.x * inv, x4.y * inv, x4.z * inv, x4.w * inv);
-    }
-    // consume the histograms of the (up to) four rows collected since the last call
-    __device__ __forceinline__ void mma_group(float *hist, const float *xs, int lane) {
-        const int kq = lane >> 4, col = lane & 15;
-#pragma unroll
-        for (int t = 0; t < HG; t++) {
-            const float b = xs[(kq * HG + t) * 16 + col];
-#pragma unroll
-            for (int tile = 0; tile < 3 * TA; tile++) {
-                int *hp = reinterpret_cast<int *>(&hist[kq * ROW + (t * 3 + tile / TA) * LP + (tile % TA) * 16 + col]);
-                const float a = (float)*hp;
-                *hp = 0;
-                acc[t][tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t][tile], 0, 0, 0);
-            }
-        }
-    }
-    // C/D layout of 16x16x4: lane holds D[row = (lane>>4)*4 + reg][col = lane&15]  (row = bin, col = i)
-    // The four waves add their slices into the (zeroed) image G one after the other with plain LDS
-    // read-add-write - within a wave every (bin, i) is touched by exactly one lane - instead of 144 float
-    // LDS atomics per wave (see the header: those serialize CU-wide).  Called by all waves of the workgroup.
-    __device__ __forceinline__ void merge(float *G, int L, int hgn, int lane, int wave) {
-        for (int turn = 0; turn < 4; turn++) {
-            if (wave == turn) {
-#pragma unroll
-                for (int t = 0; t < HG; t++) {
-                    if (t < hgn) {
-#pragma unroll
-                        for (int tile = 0; tile < 3 * TA; tile++) {
-#pragma unroll
-                            for (int reg = 0; reg < 4; reg++) {
-                                const int bin = (tile % TA) * 16 + (lane >> 4) * 4 + reg;
-                                const float v = acc[t][tile][reg];
-                                if (bin < L && v != 0.f) G[((t * 3 + tile / TA) * L + bin) * 16 + (lane & 15)] += v;
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-};
-
 // ------------------------------------------------------------------------------------------------
-// A2 backward, one side:  rows = queries (CSR, pair_map == nullptr, X = q, out = grad_q stored)
-//                         rows = keys    (CSC, pair_map = csc_pair,  X = k, out = grad_k accumulated)
+// grad_x[row, hh, :] (= | +=) sum over the row's pairs of w[m, hh] * (T[r0,.,0] + T[r1,.,1] + T[r2,.,2])
+//   rows = queries (CSR, pair_map == nullptr, stored)   |   rows = keys (CSC, pair_map = csc_pair, accumulated)
 // ------------------------------------------------------------------------------------------------
-template <int HG, int TA, bool ACCUM_OUT>
-__global__ __launch_bounds__(256, 2) void a2_bwd_side_mfma_kernel(int N, int h, int L, const float *__restrict__ go,
-                                                                  const float *__restrict__ X, const int *__restrict__ offs,
-                                                                  const int *__restrict__ pair_map, const float *__restrict__ table,
-                                                                  const int *__restrict__ rel, float *__restrict__ grad_x,
-                                                                  float *__restrict__ grad_table, int ablate) {
+template <int HG, bool ACCUM_OUT>
+__global__ __launch_bounds__(512, 8) void rows_table_sum_kernel(int N, int h, int L, const float *__restrict__ w,
+                                                                const int *__restrict__ offs, const int *__restrict__ pair_map,
+                                                                const float *__restrict__ table, const int *__restrict__ rel,
+                                                                float *__restrict__ grad_x) {
     constexpr int D = 16;
-    using TG = TableGrad<HG, TA>;
     P2_WALK_PROLOGUE
-    float *T = lds;                                     // [hgn][3][L][16]   (re-used as the merged gradient image at the end)
-    float *hist = lds + HG * 3 * L * D + wave * TG::HIST;
-    float *xs = lds + HG * 3 * L * D + 4 * TG::HIST + wave * TG::XS;
+    float *T = lds;
     stage_table<D>(T, table, L, h, h0, hgn);
-    TG tg;
-    tg.init(hist, xs, lane);
     __syncthreads();
-    int kk = 0;
-    for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
-        float4 x4[HG], acc[HG];
-        const int s = offs[row], e = offs[row + 1];
-        // largest |w| of the row -> its fixed-point scale (lane (p, c) looks at head c of pair slot p)
-        unsigned mxb = 0u;
-        for (int m0 = s; m0 < e; m0 += PPW) {
-            const int slot = m0 + p;
-            if (slot < e && c < hgn) {
-                const int m = pair_map ? pair_map[slot] : slot;
-                mxb = max(mxb, __float_as_uint(fabsf(go[(size_t)m * h + h0 + c])));
-            }
-        }
-        const typename TG::Scale sc = TG::row_scale(wave_max_u32(mxb), e - s);
+    const int wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + wave; row < N; row += gridDim.x * wpb) {
+        float4 acc[HG];
 #pragma unroll
-        for (int t = 0; t < HG; t++) {
-            x4[t] = t < hgn ? ldg4(X + (size_t)row * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
-            acc[t] = make_float4(0, 0, 0, 0);
-            if (p == 0) tg.put_x(xs, kk, t, c, x4[t], sc.inv);
-        }
+        for (int t = 0; t < HG; t++) acc[t] = make_float4(0, 0, 0, 0);
+        const int s = offs[row], e = offs[row + 1];
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int slot = m0 + p;
             if (slot < e) {
                 const int m = pair_map ? pair_map[slot] : slot;
                 const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
-                const int rc = c == 0 ? r0 : (c == 1 ? r1 : r2);
 #pragma unroll
                 for (int t = 0; t < HG; t++) {
                     if (t < hgn) {
-                        const float g = go[(size_t)m * h + h0 + t];
+                        const float g = w[(size_t)m * h + h0 + t];
                         acc[t] = fma4(g, tsum<D>(T, L, t, r0, r1, r2, c), acc[t]);
-                        if (!(ablate & 1)) tg.add(hist, kk, t, c, rc, g, sc.mul);
                     }
                 }
             }
@@ -185,60 +89,35 @@ __global__ __launch_bounds__(256, 2) void a2_bwd_side_mfma_kernel(int N, int h, 
                 }
             }
         }
-        if (++kk == 4) {
-            if (!(ablate & 2)) tg.mma_group(hist, xs, lane);
-            kk = 0;
-        }
     }
-    if (kk && !(ablate & 2)) tg.mma_group(hist, xs, lane);
-    __syncthreads();                 // every wave is done reading T
-    zero_lds<D>(T, tsz);
-    __syncthreads();
-    if (!(ablate & 4)) tg.merge(T, L, hgn, lane, wave);
-    if (!(ablate & 8)) flush_table<D>(T, grad_table, L, h, h0, hgn);
 }
 
 // ------------------------------------------------------------------------------------------------
-// A4 backward, by query: grad_attn[m,hh] = <Tv(m) + v[idx1[m]], grad_out[q]>;  grad_table from H(attn) x grad_out
+// A4 backward, per pair: grad_attn[m, hh] = <Tv(m, hh, :) + v[idx1[m], hh, :], grad_out[query, hh, :]>
 // ------------------------------------------------------------------------------------------------
-template <int HG, int TA>
-__global__ __launch_bounds__(256, 2) void a4_bwd_query_mfma_kernel(int N, int h, int L, const float *__restrict__ go,
-                                                                   const int *__restrict__ offs, const int *__restrict__ idx1,
-                                                                   const float *__restrict__ attn, const float *__restrict__ v,
-                                                                   const float *__restrict__ table, const int *__restrict__ rel,
-                                                                   float *__restrict__ grad_attn, float *__restrict__ grad_table, int ablate) {
+template <int HG>
+__global__ __launch_bounds__(512, 8) void a4_bwd_attn_kernel(int N, int h, int L, const float *__restrict__ go,
+                                                             const int *__restrict__ offs, const int *__restrict__ idx1,
+                                                             const float *__restrict__ v, const float *__restrict__ table,
+                                                             const int *__restrict__ rel, float *__restrict__ grad_attn) {
     constexpr int D = 16;
-    using TG = TableGrad<HG, TA>;
     P2_WALK_PROLOGUE
     float *T = lds;
-    float *hist = lds + HG * 3 * L * D + wave * TG::HIST;
-    float *xs = lds + HG * 3 * L * D + 4 * TG::HIST + wave * TG::XS;
     stage_table<D>(T, table, L, h, h0, hgn);
-    TG tg;
-    tg.init(hist, xs, lane);
     __syncthreads();
-    int kk = 0;
-    for (int qi = blockIdx.x * 4 + wave; qi < N; qi += gridDim.x * 4) {
+    const int wpb = blockDim.x >> 6;
+    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
         float4 g4[HG];
-        const int s = offs[qi], e = offs[qi + 1];
-        unsigned mxb = 0u;
-        for (int m0 = s; m0 < e; m0 += PPW) {
-            const int m = m0 + p;
-            if (m < e && c < hgn) mxb = max(mxb, __float_as_uint(fabsf(attn[(size_t)m * h + h0 + c])));
-        }
-        const typename TG::Scale sc = TG::row_scale(wave_max_u32(mxb), e - s);
 #pragma unroll
-        for (int t = 0; t < HG; t++) {
+        for (int t = 0; t < HG; t++)
             g4[t] = t < hgn ? ldg4(go + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
-            if (p == 0) tg.put_x(xs, kk, t, c, g4[t], sc.inv);
-        }
+        const int s = offs[qi], e = offs[qi + 1];
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int m = m0 + p;
             const bool valid = m < e;
             const int mm = valid ? m : s;
             const int j = idx1[mm];
             const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
-            const int rc = c == 0 ? r0 : (c == 1 ? r1 : r2);
             float keep = 0.f;
 #pragma unroll
             for (int t = 0; t < HG; t++) {
@@ -247,80 +126,169 @@ __global__ __launch_bounds__(256, 2) void a4_bwd_query_mfma_kernel(int N, int h,
                     float part = dot4(add4(tsum<D>(T, L, t, r0, r1, r2, c), v4), g4[t]);
                     float tot = xor_sum<1, LPG>(part);
                     if (c == t) keep = tot;
-                    if (valid && !(ablate & 1)) tg.add(hist, kk, t, c, rc, attn[(size_t)m * h + h0 + t], sc.mul);
                 }
             }
             if (valid && c < hgn) grad_attn[(size_t)m * h + h0 + c] = keep;
         }
-        if (++kk == 4) {
-            if (!(ablate & 2)) tg.mma_group(hist, xs, lane);
-            kk = 0;
-        }
     }
-    if (kk && !(ablate & 2)) tg.mma_group(hist, xs, lane);
-    __syncthreads();
-    zero_lds<D>(T, tsz);
-    __syncthreads();
-    if (!(ablate & 4)) tg.merge(T, L, hgn, lane, wave);
-    if (!(ablate & 8)) flush_table<D>(T, grad_table, L, h, h0, hgn);
 }
+
+// ------------------------------------------------------------------------------------------------
+// table gradient: grad_table[r, hh, i, ax] += sum over rows, over the row's pairs with rel[m, ax] == r, of
+//                 w[m, hh] * X[row, hh, i]
+// ------------------------------------------------------------------------------------------------
+struct FixScale {
+    float mul, inv;
+};
+// fixed-point scale of a row: maxbits = bit pattern of max|w| over its n pairs
+__device__ __forceinline__ FixScale row_scale(unsigned maxbits, int n) {
+    FixScale sc;
+    if (maxbits >= 0x7f800000u) {  // Inf / NaN among the weights
+        sc.mul = 0.f;
+        sc.inv = __uint_as_float(0x7fc00000u);
+        return sc;
+    }
+    const int E = (int)(maxbits >> 23) - 126;   // max|w| < 2^E
+    const int bits_n = 32 - __clz(max(n, 1));   // n < 2^bits_n
+    const int S = max(-126, min(126, 30 - bits_n - E));
+    sc.mul = __uint_as_float((unsigned)(S + 127) << 23);
+    sc.inv = __uint_as_float((unsigned)(127 - S) << 23);
+    return sc;
+}
+
+constexpr int TG_WAVES = 12;  // rows per group = K of the outer-product step (3 x 4)
 
 template <int HG, int TA>
-static size_t mfma_lds_bytes(int L) {
-    using TG = TableGrad<HG, TA>;
-    return ((size_t)HG * 3 * L * 16 + 4 * TG::HIST + 4 * TG::XS) * sizeof(float);
+struct TableGeo {
+    static constexpr int LP = TA * 16;                 // padded bins per axis
+    static constexpr int ROW = HG * 3 * LP + 16;       // ints per histogram row (+16: the four k-rows read by one
+                                                       // ds_read land on different banks)
+    static constexpr int TILES = HG * 3 * TA;
+    static constexpr int TPW = (TILES + TG_WAVES - 1) / TG_WAVES;
+    static constexpr size_t lds_bytes() { return (size_t)TG_WAVES * (ROW + HG * 16) * 4; }
+};
+
+template <int HG, int TA>
+__global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int h, int L, const float *__restrict__ w,
+                                                                      const float *__restrict__ X, const int *__restrict__ offs,
+                                                                      const int *__restrict__ pair_map, const int *__restrict__ rel,
+                                                                      float *__restrict__ grad_table) {
+    constexpr int D = 16, NW = TG_WAVES;
+    using G = TableGeo<HG, TA>;
+    extern __shared__ float lds[];
+    int *hist = reinterpret_cast<int *>(lds);        // [NW][ROW]
+    float *xs = lds + NW * G::ROW;                    // [NW][HG][16]: X rows of the group, scaled by 2^-S
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int C = h * D;
+    const int p = lane >> 2, c = lane & 3;            // pair slot of a pass; axis (c < 3) / head (c < hgn) of this lane
+    const int h0 = blockIdx.y * HG;
+    const int hgn = min(HG, h - h0);
+    const int kq = lane >> 4, col = lane & 15;
+
+    f32x4 acc[G::TPW];
+#pragma unroll
+    for (int i = 0; i < G::TPW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int x = threadIdx.x; x < NW * G::ROW; x += NW * 64) hist[x] = 0;
+    __syncthreads();
+
+    int *myh = hist + wave * G::ROW;
+    for (int base = blockIdx.x * NW; base < N; base += gridDim.x * NW) {
+        const int row = base + wave;
+        if (row < N) {
+            const int s = offs[row], e = offs[row + 1];
+            // largest |w| of the row -> its fixed-point scale (lane (p, c) looks at head c of pair slot p)
+            unsigned mxb = 0u;
+            for (int m0 = s; m0 < e; m0 += 16) {
+                const int slot = m0 + p;
+                if (slot < e && c < hgn) {
+                    const int m = pair_map ? pair_map[slot] : slot;
+                    mxb = max(mxb, __float_as_uint(fabsf(w[(size_t)m * h + h0 + c])));
+                }
+            }
+            const FixScale sc = row_scale(wave_max_u32(mxb), e - s);
+            if (lane < HG * 4) {  // lane = t*4 + quarter
+                const int t = lane >> 2;
+                float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < hgn) x4 = ldg4(X + (size_t)row * C + (h0 + t) * D + 4 * c);
+                *reinterpret_cast<float4 *>(&xs[(wave * HG + t) * 16 + 4 * c]) =
+                    make_float4(x4.x * sc.inv, x4.y * sc.inv, x4.z * sc.inv, x4.w * sc.inv);
+            }
+            for (int m0 = s; m0 < e; m0 += 16) {
+                const int slot = m0 + p;
+                if (slot < e && c < 3) {
+                    const int m = pair_map ? pair_map[slot] : slot;
+                    const int r = clampr(rel[m * 3 + c], L);
+#pragma unroll
+                    for (int t = 0; t < HG; t++)
+                        if (t < hgn) atomicAdd(&myh[(t * 3 + c) * G::LP + r], __float2int_rn(w[(size_t)m * h + h0 + t] * sc.mul));
+                }
+            }
+        } else if (lane < HG * 4) {
+            *reinterpret_cast<float4 *>(&xs[(wave * HG + (lane >> 2)) * 16 + 4 * c]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();  // the 12 histograms and X rows of the group are complete
+#pragma unroll
+        for (int i = 0; i < G::TPW; i++) {
+            const int tile = wave + i * NW;
+            if (tile < G::TILES) {
+                const int plane = tile / TA, bt = tile % TA, t = plane / 3;
+#pragma unroll
+                for (int ks = 0; ks < NW / 4; ks++) {
+                    const int rk = ks * 4 + kq;
+                    int *hp = &hist[rk * G::ROW + plane * G::LP + bt * 16 + col];
+                    const float a = (float)*hp;
+                    *hp = 0;
+                    const float b = xs[(rk * HG + t) * 16 + col];
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // histograms are zero again, xs may be overwritten
+    }
+    // C/D layout of 16x16x4: lane holds D[row = (lane>>4)*4 + reg][col = lane&15]  (row = bin, col = i)
+#pragma unroll
+    for (int i = 0; i < G::TPW; i++) {
+        const int tile = wave + i * NW;
+        if (tile < G::TILES) {
+            const int plane = tile / TA, bt = tile % TA, t = plane / 3, ax = plane % 3;
+            if (t < hgn) {
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int bin = bt * 16 + kq * 4 + reg;
+                    const float v = acc[i][reg];
+                    if (bin < L && v != 0.f) atomicAdd(grad_table + (((size_t)bin * h + (h0 + t)) * D + col) * 3 + ax, v);
+                }
+            }
+        }
+    }
 }
 
-// diagnostic only (tools/bench_ops.py): P2_ABLATE bit 0 = no histogram adds, 1 = no MFMA, 2 = no merge, 3 = no flush
-static int ablate_mask() {
-    static const int v = getenv("P2_ABLATE") ? atoi(getenv("P2_ABLATE")) : 0;
-    return v;
+// ---- launchers -------------------------------------------------------------------------------------------
+static int walk_blocks(int rows, int groups, int waves_per_block, int per_cu) {
+    int want = div_up(rows, waves_per_block);
+    int cap = kNumCU * per_cu;
+    if (groups > 1) cap = max(kNumCU * per_cu / groups, kNumCU / 2);
+    return max(1, min(want, cap));
 }
 
-static int mfma_blocks(int rows, int groups) {
-    int want = div_up(rows, 4);
-    int cap = kNumCU * 2;
-    if (groups > 1) cap = max(kNumCU * 2 / groups, kNumCU / 2);
-    return min(want, cap);
+template <typename F>
+static void with_heads(int h, F f) {
+    if (h >= 3) f(std::integral_constant<int, 3>{});
+    else if (h == 2) f(std::integral_constant<int, 2>{});
+    else f(std::integral_constant<int, 1>{});
 }
 
 template <int TA>
-static bool launch_a2(int N, int NK, int h, int L, const float *go, const float *q, const int *offs, const float *k,
-                      const float *table_q, const float *table_k, const int *rel, const int *co, const int *cp,
-                      float *grad_q, float *grad_k, float *gtq, float *gtk, hipStream_t st) {
-    // heads per workgroup: 3 at h >= 3 (75 KB LDS at L=64 -> two workgroups per CU)
-    auto go_hg = [&](auto tag) {
+static void launch_table_grad(int N, int h, int L, const float *w, const float *X, const int *offs, const int *pair_map,
+                              const int *rel, float *grad_table, hipStream_t st) {
+    with_heads(h, [&](auto tag) {
         constexpr int HG = decltype(tag)::value;
         const int groups = div_up(h, HG);
-        const size_t lds = mfma_lds_bytes<HG, TA>(L);
-        allow_big_lds(a2_bwd_side_mfma_kernel<HG, TA, false>, lds);
-        allow_big_lds(a2_bwd_side_mfma_kernel<HG, TA, true>, lds);
-        hipLaunchKernelGGL((a2_bwd_side_mfma_kernel<HG, TA, false>), dim3(mfma_blocks(N, groups), groups), dim3(256), lds, st,
-                           N, h, L, go, q, offs, (const int *)nullptr, table_q, rel, grad_q, gtq, ablate_mask());
-        hipLaunchKernelGGL((a2_bwd_side_mfma_kernel<HG, TA, true>), dim3(mfma_blocks(NK, groups), groups), dim3(256), lds, st,
-                           NK, h, L, go, k, co, cp, table_k, rel, grad_k, gtk, ablate_mask());
-    };
-    if (h >= 3) go_hg(std::integral_constant<int, 3>{});
-    else if (h == 2) go_hg(std::integral_constant<int, 2>{});
-    else go_hg(std::integral_constant<int, 1>{});
-    return true;
-}
-
-template <int TA>
-static bool launch_a4(int N, int h, int L, const float *go, const int *offs, const int *idx1, const float *attn, const float *v,
-                      const float *table, const int *rel, float *grad_attn, float *grad_table, hipStream_t st) {
-    auto go_hg = [&](auto tag) {
-        constexpr int HG = decltype(tag)::value;
-        const int groups = div_up(h, HG);
-        const size_t lds = mfma_lds_bytes<HG, TA>(L);
-        allow_big_lds(a4_bwd_query_mfma_kernel<HG, TA>, lds);
-        hipLaunchKernelGGL((a4_bwd_query_mfma_kernel<HG, TA>), dim3(mfma_blocks(N, groups), groups), dim3(256), lds, st,
-                           N, h, L, go, offs, idx1, attn, v, table, rel, grad_attn, grad_table, ablate_mask());
-    };
-    if (h >= 3) go_hg(std::integral_constant<int, 3>{});
-    else if (h == 2) go_hg(std::integral_constant<int, 2>{});
-    else go_hg(std::integral_constant<int, 1>{});
-    return true;
+        using G = TableGeo<HG, TA>;
+        const size_t lds = G::lds_bytes();
+        hipLaunchKernelGGL((table_grad_kernel<HG, TA>), dim3(walk_blocks(N, groups, TG_WAVES, 2), groups), dim3(TG_WAVES * 64), lds, st,
+                           N, h, L, w, X, offs, pair_map, rel, grad_table);
+    });
 }
 
 // entry points used by rpe.hip; return false when the shape is outside this file's fast path
@@ -329,16 +297,39 @@ bool a2_bwd_mfma(int N, int NK, int h, int hdim, int L, const float *go, const f
                  float *grad_q, float *grad_k, float *gtq, float *gtk) {
     if (hdim != 16 || co == nullptr || L < 1 || L > 80) return false;
     hipStream_t st = state().stream;
-    if (L <= 64) return launch_a2<4>(N, NK, h, L, go, q, offs, k, table_q, table_k, rel, co, cp, grad_q, grad_k, gtq, gtk, st);
-    return launch_a2<5>(N, NK, h, L, go, q, offs, k, table_q, table_k, rel, co, cp, grad_q, grad_k, gtq, gtk, st);
+    with_heads(h, [&](auto tag) {
+        constexpr int HG = decltype(tag)::value;
+        const int groups = div_up(h, HG);
+        const size_t lds = (size_t)HG * 3 * L * 16 * sizeof(float);
+        hipLaunchKernelGGL((rows_table_sum_kernel<HG, false>), dim3(walk_blocks(N, groups, 8, 4), groups), dim3(512), lds, st,
+                           N, h, L, go, offs, (const int *)nullptr, table_q, rel, grad_q);
+        hipLaunchKernelGGL((rows_table_sum_kernel<HG, true>), dim3(walk_blocks(NK, groups, 8, 4), groups), dim3(512), lds, st,
+                           NK, h, L, go, co, cp, table_k, rel, grad_k);
+    });
+    if (L <= 64) {
+        launch_table_grad<4>(N, h, L, go, q, offs, nullptr, rel, gtq, st);
+        launch_table_grad<4>(NK, h, L, go, k, co, cp, rel, gtk, st);
+    } else {
+        launch_table_grad<5>(N, h, L, go, q, offs, nullptr, rel, gtq, st);
+        launch_table_grad<5>(NK, h, L, go, k, co, cp, rel, gtk, st);
+    }
+    return true;
 }
 
 bool a4_bwd_mfma(int N, int h, int hdim, int L, const float *go, const int *offs, const int *idx1, const float *attn,
                  const float *v, const float *table, const int *rel, float *grad_attn, float *grad_table) {
     if (hdim != 16 || L < 1 || L > 80) return false;
     hipStream_t st = state().stream;
-    if (L <= 64) return launch_a4<4>(N, h, L, go, offs, idx1, attn, v, table, rel, grad_attn, grad_table, st);
-    return launch_a4<5>(N, h, L, go, offs, idx1, attn, v, table, rel, grad_attn, grad_table, st);
+    with_heads(h, [&](auto tag) {
+        constexpr int HG = decltype(tag)::value;
+        const int groups = div_up(h, HG);
+        const size_t lds = (size_t)HG * 3 * L * 16 * sizeof(float);
+        hipLaunchKernelGGL((a4_bwd_attn_kernel<HG>), dim3(walk_blocks(N, groups, 8, 4), groups), dim3(512), lds, st,
+                           N, h, L, go, offs, idx1, v, table, rel, grad_attn);
+    });
+    if (L <= 64) launch_table_grad<4>(N, h, L, attn, go, offs, nullptr, rel, grad_table, st);
+    else launch_table_grad<5>(N, h, L, attn, go, offs, nullptr, rel, grad_table, st);
+    return true;
 }
 
 }  // namespace p2

@@ -234,13 +234,14 @@ void attention_step1_backward_cuda_launcher_v2(int N, int M, int h, int C, const
     const LaunchState &ls = state();
     const int blocks = div_up(N, 4);
     const int *co = ls.csc_offsets, *cp = ls.csc_pair, *cq = ls.csc_query;
+    ForkJoin fj(st, fork_worthwhile((int64_t)M * h));  // grad_q and grad_k are independent
     auto run = [&](auto dtag) {
         constexpr int D = decltype(dtag)::value;
         hipLaunchKernelGGL((gather_accum_kernel<D, false>), dim3(blocks), dim3(256), 0, st, N, h, index0_offsets,
                            index1, (const int *)nullptr, grad_out, k, grad_q);
         if (co) {
             const int NK = ls.key_rows > 0 ? ls.key_rows : N;
-            hipLaunchKernelGGL((gather_accum_kernel<D, true>), dim3(div_up(NK, 4)), dim3(256), 0, st, NK, h, co, cq, cp,
+            hipLaunchKernelGGL((gather_accum_kernel<D, true>), dim3(div_up(NK, 4)), dim3(256), 0, fj.lane(1), NK, h, co, cq, cp,
                                grad_out, q, grad_k);
         }
         else

@@ -1,5 +1,6 @@
 // Launch state, row gathers (grouping / interpolation) and the CSR <-> key-major (CSC) transposition.
 #include "common.h"
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 namespace p2 {
@@ -7,6 +8,62 @@ namespace p2 {
 LaunchState &state() {
     static thread_local LaunchState s;
     return s;
+}
+
+// ---- fork / join ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kSide = 3, kMaxDev = 16;
+struct SideStreams {
+    bool ready = false;
+    hipStream_t stream[kSide];
+    hipEvent_t fork, joined[kSide];
+};
+SideStreams *side_streams() {
+    static thread_local SideStreams per_dev[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    SideStreams &s = per_dev[dev];
+    if (!s.ready) {
+        for (int i = 0; i < kSide; i++) {
+            if (hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&s.joined[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        s.ready = true;
+    }
+    return &s;
+}
+}  // namespace
+
+ForkJoin::ForkJoin(hipStream_t main, bool small) : main_(main) {
+    static const bool off = getenv("P2_NO_FORK") != nullptr;
+    enabled_ = !off && small;
+    if (enabled_) {  // the fork point is where the call starts: side lanes do not wait for this call's own lane-0 kernels
+        SideStreams *s = side_streams();
+        if (s) (void)hipEventRecord(s->fork, main_);
+        else enabled_ = false;
+    }
+}
+hipStream_t ForkJoin::lane(int i) {
+    if (i <= 0 || !enabled_) return main_;
+    SideStreams *s = side_streams();
+    if (!s) return main_;
+    i = (i - 1) % kSide;
+    if (!(used_ & (1u << i))) {
+        (void)hipStreamWaitEvent(s->stream[i], s->fork, 0);
+        used_ |= 1u << i;
+    }
+    return s->stream[i];
+}
+void ForkJoin::join() {
+    if (!used_) return;
+    SideStreams *s = side_streams();
+    for (int i = 0; i < kSide; i++)
+        if (used_ & (1u << i)) {
+            (void)hipEventRecord(s->joined[i], s->stream[i]);
+            (void)hipStreamWaitEvent(main_, s->joined[i], 0);
+        }
+    used_ = 0;
 }
 
 // ---- grouping (grouping_cuda_kernel.cu:5-25) / interpolation (interpolation_cuda_kernel.cu:5-33) ----

@@ -475,7 +475,7 @@ void dot_prod_with_idx_backward_cuda_launcher_v3(int N, int M, int h, int hdim, 
     const int *co = ls.csc_offsets, *cp = ls.csc_pair;
     const int NK = ls.key_rows > 0 ? ls.key_rows : N;
     // D=16, L<=80 with a CSC view: table gradients on the matrix cores (rpe_bwd_mfma.hip)
-    if (a2_bwd_mfma(N, NK, h, hdim, L, grad_out, q, index_q_offsets, k, table_q, table_k, rel_idx, co, cp, grad_q, grad_k,
+    if (a2_bwd_mfma(N, NK, M, h, hdim, L, grad_out, q, index_q_offsets, k, table_q, table_k, rel_idx, co, cp, grad_q, grad_k,
                     grad_table_q, grad_table_k)) {
         check_launch();
         return;
@@ -542,8 +542,10 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
     const LaunchState &ls = state();
     const int *co = ls.csc_offsets, *cp = ls.csc_pair, *cq = ls.csc_query;
     const int NK4 = ls.key_rows > 0 ? ls.key_rows : N;
-    if (co && a4_bwd_mfma(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_table)) {
-        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(div_up(NK4, 4)), dim3(256), 0, st, NK4, h, co, cq, cp, attn, grad_out, grad_v);
+    if (co && hdim == 16 && L <= 80) {
+        ForkJoin fj(st, fork_worthwhile((int64_t)M * h));  // grad_attn, grad_v and grad_table are independent
+        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(div_up(NK4, 4)), dim3(256), 0, fj.lane(2), NK4, h, co, cq, cp, attn, grad_out, grad_v);
+        a4_bwd_mfma(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_table, fj);
         check_launch();
         return;
     }

@@ -156,7 +156,18 @@ __device__ __forceinline__ FixScale row_scale(unsigned maxbits, int n) {
     return sc;
 }
 
+// value of lane t (0..2) of each quad in all four lanes of the quad (DPP quad_perm, all lanes must be active)
+__device__ __forceinline__ float quad_bcast(float v, int t) {
+    const int x = __float_as_int(v);
+    int r;
+    if (t == 0) r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, false);
+    else if (t == 1) r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, false);
+    else r = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, false);
+    return __int_as_float(r);
+}
+
 constexpr int TG_WAVES = 12;  // rows per group = K of the outer-product step (3 x 4)
+constexpr int TG_MAXP = 8;    // passes (of 16 pairs) a row may have to be walked from registers
 
 template <int HG, int TA>
 struct TableGeo {
@@ -192,41 +203,75 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
     __syncthreads();
 
     int *myh = hist + wave * G::ROW;
-    for (int base = blockIdx.x * NW; base < N; base += gridDim.x * NW) {
-        const int row = base + wave;
-        if (row < N) {
-            const int s = offs[row], e = offs[row + 1];
-            // largest |w| of the row -> its fixed-point scale (lane (p, c) looks at head c of pair slot p)
+    // Rows are dealt out dynamically inside the workgroup's contiguous share [rb, re), and a row longer than
+    // TG_MAXP passes is taken in segments of 16 * TG_MAXP pairs (the gradient is linear in the pairs, a segment
+    // is simply one more outer product with the same X row).  Key-major rows are very uneven - a stratified key
+    // is shared by several times more queries than an ordinary one - and every group ends in a barrier.
+    __shared__ int next_row;
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int rb = min(N, (int)blockIdx.x * per), re = min(N, rb + per);
+    if (threadIdx.x == 0) next_row = rb;
+    __syncthreads();
+    int row = -1, cur = 0, end = 0;
+    for (;;) {
+        if (cur >= end) {  // this wave's row is finished: take the next one
+            int r = 0;
+            if (lane == 0) r = atomicAdd(&next_row, 1);
+            r = __builtin_amdgcn_readfirstlane(r);
+            if (r < re) {
+                row = r;
+                cur = offs[row];
+                end = offs[row + 1];
+            } else {
+                row = -1;
+            }
+        }
+        if (row >= 0) {
+            const int s = cur, e = min(end, cur + 16 * TG_MAXP);
+            cur = e;
+            const int np = (e - s + 15) >> 4;  // wave passes of 16 pairs
+            // The loads of ALL passes are issued before anything depends on them - pair id, then rel index
+            // (lane c < 3: axis c) and weight (lane c < hgn: head c) - and stay in registers: one dependent
+            // chain per segment instead of one per pass, and the sweep for the fixed-point scale re-reads nothing.
+            int mreg[TG_MAXP], rreg[TG_MAXP];
+            float wreg[TG_MAXP];
+#pragma unroll
+            for (int i = 0; i < TG_MAXP; i++) {
+                const int slot = s + i * 16 + p;
+                mreg[i] = slot < e ? (pair_map ? pair_map[slot] : slot) : -1;
+            }
             unsigned mxb = 0u;
-            for (int m0 = s; m0 < e; m0 += 16) {
-                const int slot = m0 + p;
-                if (slot < e && c < hgn) {
-                    const int m = pair_map ? pair_map[slot] : slot;
-                    mxb = max(mxb, __float_as_uint(fabsf(w[(size_t)m * h + h0 + c])));
-                }
+#pragma unroll
+            for (int i = 0; i < TG_MAXP; i++) {
+                const int m = mreg[i];
+                rreg[i] = (m >= 0 && c < 3) ? rel[m * 3 + c] : 0;
+                wreg[i] = (m >= 0 && c < hgn) ? w[(size_t)m * h + h0 + c] : 0.f;
+                mxb = max(mxb, __float_as_uint(fabsf(wreg[i])));
             }
             const FixScale sc = row_scale(wave_max_u32(mxb), e - s);
-            if (lane < HG * 4) {  // lane = t*4 + quarter
+            if (lane < HG * 4) {  // lane = t*4 + quarter: the X row, scaled by 2^-S
                 const int t = lane >> 2;
                 float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (t < hgn) x4 = ldg4(X + (size_t)row * C + (h0 + t) * D + 4 * c);
                 *reinterpret_cast<float4 *>(&xs[(wave * HG + t) * 16 + 4 * c]) =
                     make_float4(x4.x * sc.inv, x4.y * sc.inv, x4.z * sc.inv, x4.w * sc.inv);
             }
-            for (int m0 = s; m0 < e; m0 += 16) {
-                const int slot = m0 + p;
-                if (slot < e && c < 3) {
-                    const int m = pair_map ? pair_map[slot] : slot;
-                    const int r = clampr(rel[m * 3 + c], L);
 #pragma unroll
-                    for (int t = 0; t < HG; t++)
-                        if (t < hgn) atomicAdd(&myh[(t * 3 + c) * G::LP + r], __float2int_rn(w[(size_t)m * h + h0 + t] * sc.mul));
+            for (int i = 0; i < TG_MAXP; i++) {
+                if (i < np) {  // wave-uniform
+                    const int r = clampr(rreg[i], L);
+#pragma unroll
+                    for (int t = 0; t < HG; t++) {
+                        const float wt = quad_bcast(wreg[i], t);  // weight of head t of this lane's pair
+                        if (t < hgn && mreg[i] >= 0 && c < 3) atomicAdd(&myh[(t * 3 + c) * G::LP + r], __float2int_rn(wt * sc.mul));
+                    }
                 }
             }
         } else if (lane < HG * 4) {
             *reinterpret_cast<float4 *>(&xs[(wave * HG + (lane >> 2)) * 16 + 4 * c]) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();  // the 12 histograms and X rows of the group are complete
+        // the 12 histograms and X rows of the group are complete; stop when no wave had a segment
+        if (!__syncthreads_or(row >= 0)) break;
 #pragma unroll
         for (int i = 0; i < G::TPW; i++) {
             const int tile = wave + i * NW;
@@ -292,43 +337,42 @@ static void launch_table_grad(int N, int h, int L, const float *w, const float *
 }
 
 // entry points used by rpe.hip; return false when the shape is outside this file's fast path
-bool a2_bwd_mfma(int N, int NK, int h, int hdim, int L, const float *go, const float *q, const int *offs, const float *k,
+bool a2_bwd_mfma(int N, int NK, int M, int h, int hdim, int L, const float *go, const float *q, const int *offs, const float *k,
                  const float *table_q, const float *table_k, const int *rel, const int *co, const int *cp,
                  float *grad_q, float *grad_k, float *gtq, float *gtk) {
     if (hdim != 16 || co == nullptr || L < 1 || L > 80) return false;
-    hipStream_t st = state().stream;
+    ForkJoin fj(state().stream, fork_worthwhile((int64_t)M * h));  // grad_q, grad_k and the two table gradients are independent
     with_heads(h, [&](auto tag) {
         constexpr int HG = decltype(tag)::value;
         const int groups = div_up(h, HG);
         const size_t lds = (size_t)HG * 3 * L * 16 * sizeof(float);
-        hipLaunchKernelGGL((rows_table_sum_kernel<HG, false>), dim3(walk_blocks(N, groups, 8, 4), groups), dim3(512), lds, st,
-                           N, h, L, go, offs, (const int *)nullptr, table_q, rel, grad_q);
-        hipLaunchKernelGGL((rows_table_sum_kernel<HG, true>), dim3(walk_blocks(NK, groups, 8, 4), groups), dim3(512), lds, st,
+        hipLaunchKernelGGL((rows_table_sum_kernel<HG, true>), dim3(walk_blocks(NK, groups, 8, 4), groups), dim3(512), lds, fj.lane(0),
                            NK, h, L, go, co, cp, table_k, rel, grad_k);
+        hipLaunchKernelGGL((rows_table_sum_kernel<HG, false>), dim3(walk_blocks(N, groups, 8, 4), groups), dim3(512), lds, fj.lane(1),
+                           N, h, L, go, offs, (const int *)nullptr, table_q, rel, grad_q);
     });
     if (L <= 64) {
-        launch_table_grad<4>(N, h, L, go, q, offs, nullptr, rel, gtq, st);
-        launch_table_grad<4>(NK, h, L, go, k, co, cp, rel, gtk, st);
+        launch_table_grad<4>(NK, h, L, go, k, co, cp, rel, gtk, fj.lane(2));
+        launch_table_grad<4>(N, h, L, go, q, offs, nullptr, rel, gtq, fj.lane(3));
     } else {
-        launch_table_grad<5>(N, h, L, go, q, offs, nullptr, rel, gtq, st);
-        launch_table_grad<5>(NK, h, L, go, k, co, cp, rel, gtk, st);
+        launch_table_grad<5>(NK, h, L, go, k, co, cp, rel, gtk, fj.lane(2));
+        launch_table_grad<5>(N, h, L, go, q, offs, nullptr, rel, gtq, fj.lane(3));
     }
     return true;
 }
 
 bool a4_bwd_mfma(int N, int h, int hdim, int L, const float *go, const int *offs, const int *idx1, const float *attn,
-                 const float *v, const float *table, const int *rel, float *grad_attn, float *grad_table) {
+                 const float *v, const float *table, const int *rel, float *grad_attn, float *grad_table, ForkJoin &fj) {
     if (hdim != 16 || L < 1 || L > 80) return false;
-    hipStream_t st = state().stream;
     with_heads(h, [&](auto tag) {
         constexpr int HG = decltype(tag)::value;
         const int groups = div_up(h, HG);
         const size_t lds = (size_t)HG * 3 * L * 16 * sizeof(float);
-        hipLaunchKernelGGL((a4_bwd_attn_kernel<HG>), dim3(walk_blocks(N, groups, 8, 4), groups), dim3(512), lds, st,
+        hipLaunchKernelGGL((a4_bwd_attn_kernel<HG>), dim3(walk_blocks(N, groups, 8, 4), groups), dim3(512), lds, fj.lane(0),
                            N, h, L, go, offs, idx1, v, table, rel, grad_attn);
     });
-    if (L <= 64) launch_table_grad<4>(N, h, L, attn, go, offs, nullptr, rel, grad_table, st);
-    else launch_table_grad<5>(N, h, L, attn, go, offs, nullptr, rel, grad_table, st);
+    if (L <= 64) launch_table_grad<4>(N, h, L, attn, go, offs, nullptr, rel, grad_table, fj.lane(1));
+    else launch_table_grad<5>(N, h, L, attn, go, offs, nullptr, rel, grad_table, fj.lane(1));
     return true;
 }
 

@@ -72,10 +72,10 @@ __device__ __forceinline__ int clampr(int r, int L) { return min(max(r, 0), L - 
 
 
 // rpe_bwd_mfma.hip
-bool a2_bwd_mfma(int N, int NK, int h, int hdim, int L, const float *go, const float *q, const int *offs, const float *k,
+bool a2_bwd_mfma(int N, int NK, int M, int h, int hdim, int L, const float *go, const float *q, const int *offs, const float *k,
                  const float *table_q, const float *table_k, const int *rel, const int *co, const int *cp,
                  float *grad_q, float *grad_k, float *gtq, float *gtk);
 bool a4_bwd_mfma(int N, int h, int hdim, int L, const float *go, const int *offs, const int *idx1, const float *attn,
-                 const float *v, const float *table, const int *rel, float *grad_attn, float *grad_table);
+                 const float *v, const float *table, const int *rel, float *grad_attn, float *grad_table, ForkJoin &fj);
 
 }  // namespace p2

@@ -53,6 +53,27 @@ __global__ __launch_bounds__(1024) void k(float4 *pts, unsigned *rank, int n, in
             unsigned long long t2 = now();
             c_issue += t1 - t0; c_wait += t2 - t1;
             __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else if (MODE == 4) {  // strided 4-byte store (the .w of 64 float4) -> time until it is acknowledged
+            reinterpret_cast<float *>(pts + pos)[3] = acc + it;
+            unsigned long long t1 = now();
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            unsigned long long t2 = now();
+            c_issue += t1 - t0; c_wait += t2 - t1;
+        } else if (MODE == 5) {  // contiguous 4-byte store (a separate distance array)
+            reinterpret_cast<float *>(rank)[pos] = acc + it;
+            unsigned long long t1 = now();
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            unsigned long long t2 = now();
+            c_issue += t1 - t0; c_wait += t2 - t1;
+        } else if (MODE == 6) {  // strided store, then DMA of ANOTHER bucket, wait for both (what an update does)
+            reinterpret_cast<float *>(pts + pos)[3] = acc + it;
+            const int pos2 = ((b * 7 + 13) % (n / 64)) * 64 + lane;
+            unsigned long long t1 = now();
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pts + pos2),
+                                             (__attribute__((address_space(3))) void *)(my), 16, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            unsigned long long t2 = now();
+            c_issue += t1 - t0; c_wait += t2 - t1;
         } else if (MODE == 3) {  // 4 DMA back to back
             for (int u = 0; u < 4; u++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pts + ((pos + u * 6400) % n)),
@@ -81,7 +102,7 @@ int main() {
     hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);                                                       \
     printf("mode %d active %2d: wave0 first %.0f second %.0f | last wave first %.0f second %.0f (cycles/iter)\n", M, ACT, h[0] / 2000.0, h[1] / 2000.0, \
            h[(ACT - 1) * 2] / 2000.0, h[(ACT - 1) * 2 + 1] / 2000.0);
-    RUN(0, 1) RUN(0, 4) RUN(0, 15) RUN(1, 1) RUN(1, 4) RUN(1, 15) RUN(2, 1) RUN(2, 15) RUN(3, 1) RUN(3, 15)
+    RUN(0, 1) RUN(0, 4) RUN(0, 15) RUN(1, 1) RUN(1, 4) RUN(1, 15) RUN(2, 1) RUN(2, 15) RUN(4, 1) RUN(4, 15) RUN(5, 1) RUN(5, 15) RUN(6, 1) RUN(6, 15)
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }

@@ -104,6 +104,41 @@ def test_attention_ops_ragged_edges(P):
     _check_attention_ops(P, random_csr_problem(64, seed=10, h=3, d=16, L=64, mean_len=1, empty_frac=0.5), use_csc=False)
 
 
+@pytest.mark.parametrize("scale", [1e-30, 1.0, 1e30])
+def test_table_gradients_fixed_point_scale(P, scale):
+    """The table-gradient histograms are accumulated in per-row fixed point (rpe_bwd_mfma.hip): the result must
+    not depend on the magnitude of the weights, rows whose weights are all zero contribute nothing, and a row
+    with weights spread over 2^40 keeps its large terms to fp32 accuracy."""
+    p = random_csr_problem(500, seed=21, h=3, d=16, L=64, mean_len=40, max_len=700)
+    rng = np.random.default_rng(3)
+    go = p["go_pairs"].copy()
+    o = p["offsets"]
+    go[o[10]:o[11]] = 0.0                                                   # an all-zero row
+    go[o[20]:o[21]] *= np.exp2(rng.integers(-40, 1, (o[21] - o[20], 1))).astype(np.float32)  # a wide row
+    go *= np.float32(scale)
+    offs, i1, rel = dev(p["offsets"]), dev(p["index_1"]), dev(p["rel_idx"])
+    q, k, tq, tk = _leaf(p["q"]), _leaf(p["k"]), _leaf(p["table_q"]), _leaf(p["table_k"])
+    out = P.dot_prod_with_idx_v3(q, offs, p["n_max"], k, i1, tq, tk, rel)
+    out.backward(dev(go))
+    args = (p["q"], p["offsets"], p["k"], p["index_1"], p["table_q"], p["table_k"], p["rel_idx"])
+    _, _, gtq, gtk = ref.dot_prod_with_idx_v3_backward(go, *args)
+    for got, want in ((_np(tq.grad), gtq), (_np(tk.grad), gtk)):
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got / np.float32(scale), want / np.float32(scale), rtol=2e-5, atol=2e-4)
+
+
+def test_table_gradients_propagate_nan(P):
+    p = random_csr_problem(200, seed=22, h=3, d=16, L=64, mean_len=20)
+    go = p["go_pairs"].copy()
+    m = p["M"] // 2
+    go[m] = np.nan
+    q, k, tq, tk = _leaf(p["q"]), _leaf(p["k"]), _leaf(p["table_q"]), _leaf(p["table_k"])
+    out = P.dot_prod_with_idx_v3(q, dev(p["offsets"]), p["n_max"], k, dev(p["index_1"]), tq, tk, dev(p["rel_idx"]))
+    out.backward(dev(go))
+    assert np.isnan(_np(tq.grad)).any() and np.isnan(_np(tk.grad)).any()   # as with the reference's atomics
+    assert np.isnan(_np(q.grad)[p["index_0"][m]]).any() and np.isnan(_np(k.grad)[p["index_1"][m]]).any()
+
+
 def test_unsupported_head_dim_is_an_error(P):
     p = random_csr_problem(32, seed=1, h=2, d=8, L=16)
     with pytest.raises(RuntimeError, match="d != 16 and d != 32"):  # attention_cuda_kernel_v2.cu:116

@@ -132,10 +132,11 @@ def _offsets_tensor(values, device):
 _GEO_STREAMS = {}
 
 
-def geometry_stream(device):
-    """Side stream for the geometry chain (FPS -> gather -> kNN): sequential by nature and one CU wide,
-    so it runs BESIDE the attention blocks of the main stream instead of in front of them."""
-    key = torch.device(device).index
+def geometry_stream(device, which=0):
+    """Side streams.  0: the sampling chain (FPS -> gather -> FPS ...), sequential by nature and one CU wide, so
+    it runs BESIDE the attention blocks of the main stream instead of in front of them.  1: the kNN queries,
+    which only consume the sampling chain's results and nobody on the chain waits for."""
+    key = (torch.device(device).index, which)
     if key not in _GEO_STREAMS:
         _GEO_STREAMS[key] = torch.cuda.Stream(device=device)
     return _GEO_STREAMS[key]
@@ -156,8 +157,10 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
     dev = xyz.device
     main = torch.cuda.current_stream(dev)
     geo = geometry_stream(dev) if overlap else main
+    knn_s = geometry_stream(dev, 1) if overlap else main
     if overlap:
         geo.wait_stream(main)
+        knn_s.wait_stream(main)
     offset_host = [int(o) for o in offset.tolist()]
     P.hint_host_offsets(offset, offset_host)
     make = states is None
@@ -168,13 +171,33 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
     def on_geo():
         return torch.cuda.stream(geo)
 
+    # Every stage's offsets follow from the host-side counts alone (transition_down_offset / stratified_new_offset
+    # are integer rules on the batch sizes), so all the small offset tensors are uploaded NOW, while both streams
+    # are empty: a torch.tensor(..., device=...) issued later would queue its host-to-device copy behind the
+    # sampler on the geometry stream and block the host - and with it the launches of the next stages - for
+    # the ~30 ms the stage-0 sampling takes.
+    plan_host = [offset_host]
+    n_trans = (len(cfg.stages) - first - 1) + (0 if cfg.stem_transformer else 1)
+    for _ in range(n_trans):
+        plan_host.append(index_build.transition_down_offset(plan_host[-1], cfg.ratio))
+    plan_dev = [offset] + [_offsets_tensor(v, dev) for v in plan_host[1:]]
+    strat_dev = [_offsets_tensor(index_build.stratified_new_offset(v, cfg.downsample_scale), dev) for v in plan_host]
+    if overlap:
+        geo.wait_stream(main)  # the uploads above were enqueued on the main stream
+    level = [0]
+
     def transition(x, off, off_host):
         """TransitionDown's sampling + grouping indices (:98-106), on the geometry stream"""
-        n_off_host = index_build.transition_down_offset(off_host, cfg.ratio)
-        n_offset = _offsets_tensor(n_off_host, dev)
+        level[0] += 1
+        n_off_host, n_offset = plan_host[level[0]], plan_dev[level[0]]
         idx = timer.run("fps/transition", P.furthestsampling, x, off, n_offset)
         n_xyz = x[idx.long(), :].contiguous()
-        knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, x, n_xyz, off, n_offset)
+        if overlap:  # the grouping query leaves the sampling chain here
+            knn_s.wait_stream(geo)
+            for t in (x, n_xyz, off, n_offset):
+                t.record_stream(knn_s)
+        with torch.cuda.stream(knn_s):
+            knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, x, n_xyz, off, n_offset)
         return n_xyz, n_offset, n_off_host, knn_idx
 
     cur_xyz, cur_off, cur_off_host = xyz, offset, offset_host
@@ -186,7 +209,7 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
         st = cfg.stages[si]
         # ---- geometry stream: samples for this stage's stratified keys, then on to the next stage ----
         with on_geo():
-            new_offset = _offsets_tensor(index_build.stratified_new_offset(cur_off_host, cfg.downsample_scale), dev)
+            new_offset = strat_dev[level[0]]
             ds = timer.run("fps/stratified", P.furthestsampling, cur_xyz, cur_off, new_offset)
             ev_ds = torch.cuda.Event()
             ev_ds.record(geo)
@@ -218,7 +241,9 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
             cur_xyz, cur_off, cur_off_host, knn_idx = nxt
             results[-1]["transition_knn"] = knn_idx
     # Upsample chain (:479-480): interpolate from the coarse stage back to each finer one (kNN k=up_k)
-    with on_geo():
+    if overlap:
+        knn_s.wait_stream(geo)
+    with torch.cuda.stream(knn_s):
         coarse_xyz, coarse_off = stack.pop()
         while stack:
             fine_xyz, fine_off = stack.pop()
@@ -226,4 +251,5 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
             coarse_xyz, coarse_off = fine_xyz, fine_off
     if overlap:
         main.wait_stream(geo)
+        main.wait_stream(knn_s)
     return states, results

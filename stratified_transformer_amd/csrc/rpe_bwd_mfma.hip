@@ -174,9 +174,11 @@ struct TableGeo {
     static constexpr int LP = TA * 16;                 // padded bins per axis
     static constexpr int ROW = HG * 3 * LP + 16;       // ints per histogram row (+16: the four k-rows read by one
                                                        // ds_read land on different banks)
-    static constexpr int TILES = HG * 3 * TA;
-    static constexpr int TPW = (TILES + TG_WAVES - 1) / TG_WAVES;
-    static constexpr size_t lds_bytes() { return (size_t)TG_WAVES * (ROW + HG * 16) * 4; }
+    static constexpr int GROUPS = HG * TA;             // (head, 16-bin tile); a wave owns whole groups = 3 axis tiles each
+    static constexpr int GPW = (GROUPS + TG_WAVES - 1) / TG_WAVES;
+    static constexpr size_t walk_bytes() { return (size_t)TG_WAVES * (ROW + HG * 16) * 4; }
+    static constexpr size_t flush_bytes() { return (size_t)TG_WAVES * 16 * 48 * 4; }  // one group per wave at a time
+    static constexpr size_t lds_bytes() { return walk_bytes() > flush_bytes() ? walk_bytes() : flush_bytes(); }
 };
 
 template <int HG, int TA>
@@ -196,9 +198,11 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
     const int hgn = min(HG, h - h0);
     const int kq = lane >> 4, col = lane & 15;
 
-    f32x4 acc[G::TPW];
+    f32x4 acc[G::GPW][3];  // [owned group][axis]
 #pragma unroll
-    for (int i = 0; i < G::TPW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < G::GPW; i++)
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) acc[i][ax] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int x = threadIdx.x; x < NW * G::ROW; x += NW * 64) hist[x] = 0;
     __syncthreads();
 
@@ -273,36 +277,51 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
         // the 12 histograms and X rows of the group are complete; stop when no wave had a segment
         if (!__syncthreads_or(row >= 0)) break;
 #pragma unroll
-        for (int i = 0; i < G::TPW; i++) {
-            const int tile = wave + i * NW;
-            if (tile < G::TILES) {
-                const int plane = tile / TA, bt = tile % TA, t = plane / 3;
+        for (int i = 0; i < G::GPW; i++) {
+            const int g = wave + i * NW;  // group = (head t, bin tile bt)
+            if (g < G::GROUPS) {
+                const int t = g / TA, bt = g % TA;
 #pragma unroll
                 for (int ks = 0; ks < NW / 4; ks++) {
                     const int rk = ks * 4 + kq;
-                    int *hp = &hist[rk * G::ROW + plane * G::LP + bt * 16 + col];
-                    const float a = (float)*hp;
-                    *hp = 0;
                     const float b = xs[(rk * HG + t) * 16 + col];
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        int *hp = &hist[rk * G::ROW + (t * 3 + ax) * G::LP + bt * 16 + col];
+                        const float a = (float)*hp;
+                        *hp = 0;
+                        acc[i][ax] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][ax], 0, 0, 0);
+                    }
                 }
             }
         }
         __syncthreads();  // histograms are zero again, xs may be overwritten
     }
-    // C/D layout of 16x16x4: lane holds D[row = (lane>>4)*4 + reg][col = lane&15]  (row = bin, col = i)
+    // Flush.  C/D layout of 16x16x4: lane holds D[row = (lane>>4)*4 + reg][col = lane&15]  (row = bin, col = i).
+    // In the [L, h, 16, 3] table the 48 floats of one (bin, head) are contiguous, and a wave owns all three axis
+    // tiles of its groups: the group goes through LDS in table order and leaves as 12 wave instructions of 64
+    // consecutive floats (global float atomics run at full rate only for contiguous 128-256 B segments,
+    // MI355X_MICROARCH.md; one dword per lane with a 12-byte stride was 3-5x slower).
+    __syncthreads();  // the walk's LDS is free
+    float *stage = lds + wave * (16 * 48);
 #pragma unroll
-    for (int i = 0; i < G::TPW; i++) {
-        const int tile = wave + i * NW;
-        if (tile < G::TILES) {
-            const int plane = tile / TA, bt = tile % TA, t = plane / 3, ax = plane % 3;
+    for (int i = 0; i < G::GPW; i++) {
+        const int g = wave + i * NW;
+        if (g < G::GROUPS) {
+            const int t = g / TA, bt = g % TA;
             if (t < hgn) {
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    const int bin = bt * 16 + kq * 4 + reg;
-                    const float v = acc[i][reg];
-                    if (bin < L && v != 0.f) atomicAdd(grad_table + (((size_t)bin * h + (h0 + t)) * D + col) * 3 + ax, v);
+                for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) stage[((kq * 4 + reg) * 16 + col) * 3 + ax] = acc[i][ax][reg];
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // this wave's LDS writes have landed (the region is private to the wave)
+#pragma unroll
+                for (int x = lane; x < 16 * 48; x += 64) {
+                    const int bin = bt * 16 + x / 48;
+                    const float v = stage[x];
+                    if (bin < L && v != 0.f) atomicAdd(grad_table + ((size_t)bin * h + (h0 + t)) * 48 + x % 48, v);
                 }
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // reads done before the next group overwrites the stage
             }
         }
     }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void a1_fwd_kernel(int N, int h, const float *
         const bool valid = m < e;
         const int j = idx1[valid ? m : s];
         const float *krow = k + (size_t)j * C + 4 * c;
-        for (int hb = 0; hb < h; hb += LPG) {
+        for (int hb = blockIdx.y * LPG; hb < h; hb += gridDim.y * LPG) {  // head groups over blockIdx.y on small clouds
             float keep = 0.f;
 #pragma unroll
             for (int t = 0; t < LPG; t++) {
@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void gather_accum_kernel(int N, int h, const i
     const int C = h * D;
     const int p = lane / LPG, c = lane % LPG;
     const int s = offs[row], e = offs[row + 1];
-    for (int hb = 0; hb < h; hb += HC) {
+    // head chunks are spread over blockIdx.y: the index walk is repeated per chunk anyway, and on the late
+    // stages (few rows, many heads) one wave per row leaves most of the chip idle
+    for (int hb = blockIdx.y * HC; hb < h; hb += gridDim.y * HC) {
         float4 acc[HC];
 #pragma unroll
         for (int t = 0; t < HC; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -219,8 +221,8 @@ void attention_step1_forward_cuda_launcher_v2(int N, int M, int h, int C, const 
     const int blocks = div_up(N, 4);
     const size_t lds = 4 * (size_t)C * sizeof(float);
     dispatch_d(C / h,
-               [&] { hipLaunchKernelGGL(a1_fwd_kernel<16>, dim3(blocks), dim3(256), lds, st, N, h, q, k, index0_offsets, index1, attn); },
-               [&] { hipLaunchKernelGGL(a1_fwd_kernel<32>, dim3(blocks), dim3(256), lds, st, N, h, q, k, index0_offsets, index1, attn); });
+               [&] { hipLaunchKernelGGL(a1_fwd_kernel<16>, dim3(blocks, N < 20000 ? div_up(h, 4) : 1), dim3(256), lds, st, N, h, q, k, index0_offsets, index1, attn); },
+               [&] { hipLaunchKernelGGL(a1_fwd_kernel<32>, dim3(blocks, N < 20000 ? div_up(h, 8) : 1), dim3(256), lds, st, N, h, q, k, index0_offsets, index1, attn); });
     check_launch();
 }
 
@@ -237,11 +239,12 @@ void attention_step1_backward_cuda_launcher_v2(int N, int M, int h, int C, const
     ForkJoin fj(st, fork_worthwhile((int64_t)M * h));  // grad_q and grad_k are independent
     auto run = [&](auto dtag) {
         constexpr int D = decltype(dtag)::value;
-        hipLaunchKernelGGL((gather_accum_kernel<D, false>), dim3(blocks), dim3(256), 0, st, N, h, index0_offsets,
+        const int chunks = div_up(h, 4);
+        hipLaunchKernelGGL((gather_accum_kernel<D, false>), dim3(blocks, chunks), dim3(256), 0, st, N, h, index0_offsets,
                            index1, (const int *)nullptr, grad_out, k, grad_q);
         if (co) {
             const int NK = ls.key_rows > 0 ? ls.key_rows : N;
-            hipLaunchKernelGGL((gather_accum_kernel<D, true>), dim3(div_up(NK, 4)), dim3(256), 0, fj.lane(1), NK, h, co, cq, cp,
+            hipLaunchKernelGGL((gather_accum_kernel<D, true>), dim3(div_up(NK, 4), chunks), dim3(256), 0, fj.lane(1), NK, h, co, cq, cp,
                                grad_out, q, grad_k);
         }
         else

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void key_accum_kernel(int N, int h, const int 
     const int C = h * D;
     const int p = lane / LPG, c = lane % LPG;
     const int s = offs[row], e = offs[row + 1];
-    for (int hb = 0; hb < h; hb += HC) {
+    for (int hb = blockIdx.y * HC; hb < h; hb += gridDim.y * HC) {  // head chunks over blockIdx.y (attention.hip)
         float4 acc[HC];
 #pragma unroll
         for (int t = 0; t < HC; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -544,7 +544,7 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
     const int NK4 = ls.key_rows > 0 ? ls.key_rows : N;
     if (co && hdim == 16 && L <= 80) {
         ForkJoin fj(st, fork_worthwhile((int64_t)M * h));  // grad_attn, grad_v and grad_table are independent
-        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(div_up(NK4, 4)), dim3(256), 0, fj.lane(2), NK4, h, co, cq, cp, attn, grad_out, grad_v);
+        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(div_up(NK4, 4), div_up(h, 4)), dim3(256), 0, fj.lane(2), NK4, h, co, cq, cp, attn, grad_out, grad_v);
         a4_bwd_mfma(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_table, fj);
         check_launch();
         return;
@@ -557,7 +557,7 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
             hipLaunchKernelGGL((a4_bwd_query_kernel<Dc, HGc, false>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \
                                lds_bytes, st, N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, \
                                grad_v, grad_table);                                                                         \
-            hipLaunchKernelGGL(key_accum_kernel<Dc>, dim3(div_up(NK4, 4)), dim3(256), 0, st, NK4, h, co, cq, cp, attn, grad_out, \
+            hipLaunchKernelGGL(key_accum_kernel<Dc>, dim3(div_up(NK4, 4), div_up(h, 4)), dim3(256), 0, st, NK4, h, co, cq, cp, attn, grad_out, \
                                grad_v);                                                                                     \
         } else {                                                                                                            \
             hipLaunchKernelGGL((a4_bwd_query_kernel<Dc, HGc, true>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \

@@ -71,6 +71,74 @@ __global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(int N, int h, int 
     }
 }
 
+// Few rows, many heads (the late stages: h = 12 / 24 gives only 4 / 2 pairs per wave pass): one WORKGROUP per
+// query, its four waves stride over the pairs together and combine their partial max / sum through LDS.
+// Same arithmetic per element; the sum's order differs (fp32 tolerance, like the wave version's butterfly).
+__device__ __forceinline__ float block_combine(float v, int hp, bool is_max, float *red, int wave, int lane) {
+    v = is_max ? slot_max(v, hp) : slot_sum(v, hp);
+    __syncthreads();  // red[] from the previous use has been read
+    if (lane < hp) red[wave * 64 + lane] = v;
+    __syncthreads();
+    float r = red[lane % hp];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        const float o = red[w * 64 + lane % hp];
+        r = is_max ? fmaxf(r, o) : r + o;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void seg_softmax_fwd_block_kernel(int N, int h, int hp, const float *__restrict__ src,
+                                                                    const int *__restrict__ offs, float *__restrict__ out) {
+    __shared__ float red[4 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qi = blockIdx.x;
+    const int ppw = 64 / hp, p = lane / hp + wave * ppw, c = lane % hp, stride = 4 * ppw;
+    const int s = offs[qi], e = offs[qi + 1];
+    if (e <= s) return;
+    for (int hb = 0; hb < h; hb += hp) {
+        const int hh = hb + c;
+        const bool hv = hh < h;
+        float mx = -INFINITY;
+        for (int m = s + p; m < e; m += stride)
+            if (hv) mx = fmaxf(mx, src[(size_t)m * h + hh]);
+        mx = block_combine(mx, hp, true, red, wave, lane);
+        float sum = 0.f;
+        for (int m = s + p; m < e; m += stride)
+            if (hv) {
+                const float ex = expf(src[(size_t)m * h + hh] - mx);
+                out[(size_t)m * h + hh] = ex;
+                sum += ex;
+            }
+        sum = block_combine(sum, hp, false, red, wave, lane);
+        for (int m = s + p; m < e; m += stride)
+            if (hv) out[(size_t)m * h + hh] = out[(size_t)m * h + hh] / sum;
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_softmax_bwd_block_kernel(int N, int h, int hp, const float *__restrict__ y,
+                                                                    const float *__restrict__ gy, const int *__restrict__ offs,
+                                                                    float *__restrict__ gx) {
+    __shared__ float red[4 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qi = blockIdx.x;
+    const int ppw = 64 / hp, p = lane / hp + wave * ppw, c = lane % hp, stride = 4 * ppw;
+    const int s = offs[qi], e = offs[qi + 1];
+    if (e <= s) return;
+    for (int hb = 0; hb < h; hb += hp) {
+        const int hh = hb + c;
+        const bool hv = hh < h;
+        float dot = 0.f;
+        for (int m = s + p; m < e; m += stride)
+            if (hv) dot = fmaf(y[(size_t)m * h + hh], gy[(size_t)m * h + hh], dot);
+        dot = block_combine(dot, hp, false, red, wave, lane);
+        for (int m = s + p; m < e; m += stride)
+            if (hv) gx[(size_t)m * h + hh] = y[(size_t)m * h + hh] * (gy[(size_t)m * h + hh] - dot);
+    }
+}
+
+static bool few_rows_many_heads(int N, int h) { return N < 20000 && h > 4; }
+
 static int next_pow2_le64(int h) {
     int hp = 1;
     while (hp < h && hp < 64) hp <<= 1;
@@ -85,14 +153,20 @@ extern "C" {
 
 void segment_softmax_forward_launcher(int N, int M, int h, const float *src, const int *offsets, float *out) {
     if (N <= 0 || M <= 0) return;
-    hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), src, offsets, out);
+    if (few_rows_many_heads(N, h))
+        hipLaunchKernelGGL(seg_softmax_fwd_block_kernel, dim3(N), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), src, offsets, out);
+    else
+        hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), src, offsets, out);
     check_launch();
 }
 
 void segment_softmax_backward_launcher(int N, int M, int h, const float *out, const float *grad_out,
                                        const int *offsets, float *grad_src) {
     if (N <= 0 || M <= 0) return;
-    hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), out, grad_out, offsets, grad_src);
+    if (few_rows_many_heads(N, h))
+        hipLaunchKernelGGL(seg_softmax_bwd_block_kernel, dim3(N), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), out, grad_out, offsets, grad_src);
+    else
+        hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), out, grad_out, offsets, grad_src);
     check_launch();
 }
 

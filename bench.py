@@ -129,10 +129,17 @@ def roofline(comp, run):
                     note="kNN is VALU/latency-bound; see DESIGN.md")
     dur_s = comp[name]["ms_per_call"] / 1e3
     achieved = bytes_per_launch / dur_s / 1e9
+    # HBM-side bytes per launch from the committed PMC passes (tools/pmc_traffic.py: separate FETCH_SIZE and
+    # WRITE_SIZE runs of this command, (2 x FETCH_SIZE + WRITE_SIZE) x 1024): the group's bytes per pass over the
+    # group's op launches per pass
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get(name)
+        group = name.split("/")[0] if name.split("/")[0] in ("fps", "knn") else name.split("/")[0]
+        per_pass = json.load(open(pmc)).get("bytes_per_pass_by_group", {}).get(group)
+        launches = sum(c["calls_per_step"] for k, c in comp.items() if k.split("/")[0] == group)
+        if per_pass and launches:
+            traffic = int(per_pass / launches)
     return dict(bound="hbm", kernel=name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, algorithmic_bytes_per_launch=int(bytes_per_launch),
                 mean_launch_ms=round(comp[name]["ms_per_call"], 4), note=note)

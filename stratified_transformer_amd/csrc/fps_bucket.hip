@@ -159,7 +159,7 @@ __global__ __launch_bounds__(VER_T) void fps_verify_threshold_kernel(int Bref, i
     const int m = min(end_m - start_m, end_n - start_n);  // the identity prefix cannot be longer than the cloud
     if (first_bad[bid] < jlo) return;
     const int j = jlo + blockIdx.x * VER_T + threadIdx.x;
-    __shared__ float sx[VER_T], sy[VER_T], sz[VER_T];
+    __shared__ float4 s4[VER_T];
     const int jmax = min(jlo + (int)(blockIdx.x + 1) * VER_T, m);  // tiles of samples needed by this block: i < jmax
     if (jlo + (int)blockIdx.x * VER_T >= m) return;
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -168,10 +168,14 @@ __global__ __launch_bounds__(VER_T) void fps_verify_threshold_kernel(int Bref, i
     for (int i0 = 0; i0 < jmax; i0 += VER_T) {
         __syncthreads();
         const int i = i0 + threadIdx.x;
-        if (i < jmax) { sx[threadIdx.x] = xyz[(size_t)(start_n + i) * 3]; sy[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 1]; sz[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 2]; }
+        if (i < jmax) s4[threadIdx.x] = make_float4(xyz[(size_t)(start_n + i) * 3], xyz[(size_t)(start_n + i) * 3 + 1], xyz[(size_t)(start_n + i) * 3 + 2], 0.f);
         __syncthreads();
         const int lim = min(VER_T, j - i0);  // samples i < j
-        for (int t = 0; t < lim; t++) D = fminf(D, sqd(px - sx[t], py - sy[t], pz - sz[t]));
+#pragma unroll 8
+        for (int t = 0; t < lim; t++) {
+            const float4 sp = s4[t];
+            D = fminf(D, sqd(px - sp.x, py - sp.y, pz - sp.z));
+        }
     }
     if (j < m) T[start_n + j] = ((unsigned long long)__float_as_uint(D) << 32) | (unsigned)key_of(0.f, j, Bref, log2B);
 }
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(VER_T) void fps_verify_scan_kernel(int Bref, int lo
     const int m = min(min(end_m - start_m, n), jhi_cap);
     if (first_bad[bid] < jlo || (int)blockIdx.x * VER_T >= n) return;
     const int x = blockIdx.x * VER_T + threadIdx.x;
-    __shared__ float sx[VER_T], sy[VER_T], sz[VER_T];
+    __shared__ float4 s4[VER_T];
     __shared__ unsigned long long sT[VER_T];
     __shared__ int s_fb;
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -204,16 +208,26 @@ __global__ __launch_bounds__(VER_T) void fps_verify_scan_kernel(int Bref, int lo
         if (i0 > s_fb) break;  // block-uniform: an earlier step already failed somewhere
         const int i = i0 + threadIdx.x;
         if (i < m - 1) {
-            sx[threadIdx.x] = xyz[(size_t)(start_n + i) * 3]; sy[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 1]; sz[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 2];
+            s4[threadIdx.x] = make_float4(xyz[(size_t)(start_n + i) * 3], xyz[(size_t)(start_n + i) * 3 + 1], xyz[(size_t)(start_n + i) * 3 + 2], 0.f);
             sT[threadIdx.x] = (i + 1 >= jlo) ? T[start_n + i + 1] : ~0ull;
+        } else {
+            s4[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sT[threadIdx.x] = ~0ull;  // never violated
         }
         __syncthreads();
         const int lim = min(VER_T, m - 1 - i0);
         if (live && bad == 0x7fffffff) {
-            for (int t = 0; t < lim; t++) {
-                D = fminf(D, sqd(px - sx[t], py - sy[t], pz - sz[t]));
-                const unsigned long long key = ((unsigned long long)__float_as_uint(D) << 32) | rk;
-                if (key > sT[t]) { bad = i0 + t + 1; break; }
+            // no early exit inside a tile: eight samples per trip, the LDS reads of a trip are independent of its
+            // compares (with a break after every sample each trip waited a full LDS round trip)
+            for (int t0 = 0; t0 < lim; t0 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int t = t0 + u;  // t < VER_T always (VER_T % 8 == 0); padded entries cannot fail
+                    const float4 sp = s4[t];
+                    D = fminf(D, sqd(px - sp.x, py - sp.y, pz - sp.z));
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(D) << 32) | rk;
+                    if (key > sT[t] && bad == 0x7fffffff) bad = i0 + t + 1;
+                }
             }
         }
     }
@@ -240,17 +254,21 @@ __global__ __launch_bounds__(VER_T) void fps_rebuild_kernel(const float *__restr
     const int v = first_bad[bid];
     if (v <= prev || v <= 1 || (int)blockIdx.x * VER_T >= n) return;
     const int x = blockIdx.x * VER_T + threadIdx.x;
-    __shared__ float sx[VER_T], sy[VER_T], sz[VER_T];
+    __shared__ float4 s4[VER_T];
     float px = 0.f, py = 0.f, pz = 0.f;
     if (x < n) { px = xyz[(size_t)(start_n + x) * 3]; py = xyz[(size_t)(start_n + x) * 3 + 1]; pz = xyz[(size_t)(start_n + x) * 3 + 2]; }
     float D = 1e10f;
     for (int i0 = 0; i0 < v - 1; i0 += VER_T) {
         __syncthreads();
         const int i = i0 + threadIdx.x;
-        if (i < v - 1) { sx[threadIdx.x] = xyz[(size_t)(start_n + i) * 3]; sy[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 1]; sz[threadIdx.x] = xyz[(size_t)(start_n + i) * 3 + 2]; }
+        if (i < v - 1) s4[threadIdx.x] = make_float4(xyz[(size_t)(start_n + i) * 3], xyz[(size_t)(start_n + i) * 3 + 1], xyz[(size_t)(start_n + i) * 3 + 2], 0.f);
         __syncthreads();
         const int lim = min(VER_T, v - 1 - i0);
-        for (int t = 0; t < lim; t++) D = fminf(D, sqd(px - sx[t], py - sy[t], pz - sz[t]));
+#pragma unroll 8
+        for (int t = 0; t < lim; t++) {
+            const float4 sp = s4[t];
+            D = fminf(D, sqd(px - sp.x, py - sp.y, pz - sp.z));
+        }
     }
     if (x < n) reinterpret_cast<float *>(pts + inv[start_n + x])[3] = D;
 }

@@ -72,12 +72,13 @@ class Timer:
     """Per-component device timing with events on torch's current stream (the stream every HIP launch
     of this package uses).  Disabled timers cost nothing."""
 
-    def __init__(self, enabled=True):
+    def __init__(self, enabled=True, only=None):
         self.enabled = enabled
+        self.only = only  # optional tuple of name prefixes: everything else runs untimed
         self.spans = []
 
     def run(self, name, fn, *a, **k):
-        if not self.enabled:
+        if not self.enabled or (self.only is not None and not name.startswith(self.only)):
             return fn(*a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -161,6 +162,7 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
     if overlap:
         geo.wait_stream(main)
         knn_s.wait_stream(main)
+        geometry_stream(dev, 2).wait_stream(main)
     offset_host = [int(o) for o in offset.tolist()]
     P.hint_host_offsets(offset, offset_host)
     make = states is None
@@ -204,52 +206,87 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
     if not cfg.stem_transformer:  # Stratified.forward :458-462: a TransitionDown precedes the first attention stage
         with on_geo():
             cur_xyz, cur_off, cur_off_host, _ = transition(cur_xyz, cur_off, cur_off_host)
-    stack = []
-    for si in range(first, len(cfg.stages)):
-        st = cfg.stages[si]
-        # ---- geometry stream: samples for this stage's stratified keys, then on to the next stage ----
+    # The loop is software-pipelined on the HOST: while the attention blocks of stage s run on the main stream,
+    # the geometry of stage s+1 is already queued on the geometry stream and its index build - whose two host
+    # syncs (key width, pair count) would otherwise stop the launches - is done on a third stream.
+    idx_s = geometry_stream(dev, 2) if overlap else main
+    stages = list(range(first, len(cfg.stages)))
+    clouds = {}   # si -> (xyz, off, off_host)
+    geo_out = {}  # si -> (ds, ev_ds, knn_idx or None)
+    idx_out = {}  # si -> (even, odd, ev_idx)
+    clouds[first] = (cur_xyz, cur_off, cur_off_host)
+
+    def geometry(si):
+        """geometry stream: samples for this stage's stratified keys, then on to the next stage's points"""
+        x, off, off_host = clouds[si]
         with on_geo():
-            new_offset = strat_dev[level[0]]
-            ds = timer.run("fps/stratified", P.furthestsampling, cur_xyz, cur_off, new_offset)
+            ds = timer.run("fps/stratified", P.furthestsampling, x, off, strat_dev[level[0]])
             ev_ds = torch.cuda.Event()
             ev_ds.record(geo)
-            nxt = None
+            knn_idx = None
             if si < len(cfg.stages) - 1:
-                nxt = transition(cur_xyz, cur_off, cur_off_host)
-        # ---- main stream: index build + attention of this stage ----
+                n_xyz, n_off, n_off_host, knn_idx = transition(x, off, off_host)
+                clouds[si + 1] = (n_xyz, n_off, n_off_host)
+        geo_out[si] = (ds, ev_ds, knn_idx)
+
+    def index(si):
+        x, off, _ = clouds[si]
+        ds, ev_ds, _ = geo_out[si]
+        st = cfg.stages[si]
         if overlap:
-            main.wait_event(ev_ds)
-            for t in (ds, cur_xyz, cur_off):
-                t.record_stream(main)
+            idx_s.wait_event(ev_ds)
+            for t in (ds, x, off):
+                t.record_stream(idx_s)
+        with torch.cuda.stream(idx_s):
+            if use_hip_index:
+                even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds)
+            else:
+                parts = timer.run("index/partition", index_build.stage_partitions, x, off, st.window_size)
+                even = timer.run("index/pairs", index_build.build_block_index, x, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)
+                odd = timer.run("index/pairs", index_build.build_block_index, x, parts["small_shift"], parts["large_shift"], ds, st.window_size, st.quant_size, True)
+            ev_idx = torch.cuda.Event()
+            ev_idx.record(idx_s)
+        idx_out[si] = (even, odd, ev_idx)
+
+    geometry(first)
+    index(first)
+    for si in stages:
+        st = cfg.stages[si]
+        x, off, _ = clouds[si]
+        if si + 1 in stages:
+            geometry(si + 1)
+        if si == stages[-1]:
+            # Upsample chain (:479-480): interpolate from the coarse stage back to each finer one (kNN k=up_k);
+            # every cloud is queued by now
+            if overlap:
+                knn_s.wait_stream(geo)
+            with torch.cuda.stream(knn_s):
+                for fine in reversed(stages[:-1]):
+                    cx, coff, _ = clouds[fine + 1]
+                    fx, foff, _ = clouds[fine]
+                    timer.run("knn/k3", P.knnquery, cfg.up_k, cx, fx, coff, foff)
+        even, odd, ev_idx = idx_out[si]
+        ds, _, knn_idx = geo_out[si]
+        if overlap:
+            main.wait_event(ev_idx)
+            for t in (x, off, ds, even.index_1, even.offsets, even.rel_idx, odd.index_1, odd.offsets, odd.rel_idx):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
         if make:
-            states.append(make_stage_state(cur_xyz, cur_off, st, seed + si))
+            states.append(make_stage_state(x, off, st, seed + si))
         state = states[si - first]
-        state.xyz, state.offset = cur_xyz, cur_off
-        if use_hip_index:
-            even, odd, _ = timer.run("index/build", index_build.stage_index_hip, cur_xyz, cur_off, st.window_size, st.quant_size, ds)
-        else:
-            parts = timer.run("index/partition", index_build.stage_partitions, cur_xyz, cur_off, st.window_size)
-            even = timer.run("index/pairs", index_build.build_block_index, cur_xyz, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)
-            odd = timer.run("index/pairs", index_build.build_block_index, cur_xyz, parts["small_shift"], parts["large_shift"], ds, st.window_size, st.quant_size, True)
+        state.xyz, state.offset = x, off
         out = None
         for b in range(st.depth):
             out = attention_block(state, even if b % 2 == 0 else odd, timer)
-        results.append(dict(stage=si, n=cur_xyz.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),
+        results.append(dict(stage=si, n=x.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),
                             even=even, odd=odd, downsample_idx=ds, out=out))
-        stack.append((cur_xyz, cur_off))
-        if nxt is not None:
-            cur_xyz, cur_off, cur_off_host, knn_idx = nxt
+        if knn_idx is not None:
             results[-1]["transition_knn"] = knn_idx
-    # Upsample chain (:479-480): interpolate from the coarse stage back to each finer one (kNN k=up_k)
-    if overlap:
-        knn_s.wait_stream(geo)
-    with torch.cuda.stream(knn_s):
-        coarse_xyz, coarse_off = stack.pop()
-        while stack:
-            fine_xyz, fine_off = stack.pop()
-            timer.run("knn/k3", P.knnquery, cfg.up_k, coarse_xyz, fine_xyz, coarse_off, fine_off)
-            coarse_xyz, coarse_off = fine_xyz, fine_off
+        if si + 1 in stages:
+            index(si + 1)
     if overlap:
         main.wait_stream(geo)
         main.wait_stream(knn_s)
+        main.wait_stream(idx_s)
     return states, results

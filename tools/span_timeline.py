@@ -1,0 +1,31 @@
+"""Un-profiled timeline of one scene pass from the pipeline's own event spans (diagnostic; GPU box only)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stratified_transformer_amd import scene, pipeline
+
+cfg = pipeline.s3dis_config()
+xyz = torch.from_numpy(scene.make_room(100000, 0)).cuda()
+off = torch.tensor([100000], dtype=torch.int32, device='cuda')
+states, _ = pipeline.scene_pass(xyz, off, cfg)
+pipeline.scene_pass(xyz, off, cfg, states)
+torch.cuda.synchronize()
+timer = pipeline.Timer(True)
+ref = torch.cuda.Event(enable_timing=True)
+ref.record()
+pipeline.scene_pass(xyz, off, cfg, states, timer)
+end = torch.cuda.Event(enable_timing=True)
+end.record()
+torch.cuda.synchronize()
+print('pass %.2f ms' % ref.elapsed_time(end))
+rows = [(ref.elapsed_time(e0), ref.elapsed_time(e1), name) for name, e0, e1 in timer.spans]
+rows.sort()
+cur = None
+for s, e, n in rows:
+    key = n.split('/')[0] if n.startswith('attn') else n
+    if cur and cur[2] == key and s - cur[1] < 0.3:
+        cur[1] = max(cur[1], e); cur[3] += 1
+    else:
+        if cur: print('%7.2f -> %7.2f  %-16s x%d' % tuple(cur))
+        cur = [s, e, key, 1]
+print('%7.2f -> %7.2f  %-16s x%d' % tuple(cur))

@@ -527,3 +527,26 @@ def test_fps_of_an_fps_ordered_cloud_is_verified_in_parallel(P):
     b = _np(P.furthestsampling(x, off, dev(np.array([1500], np.int32))))
     full = ref.furthestsampling(broken, np.array([3001], np.int32), np.array([1500], np.int32))
     assert np.array_equal(b, full) and np.array_equal(a, full[:376])
+
+
+def test_scene_pass_scannet_config_three_rooms(P):
+    """BASELINE configs 4 / 5 in small: the ScanNet yaml (five stages, L = 80, downsample_scale 4, a TransitionDown in
+    front of the first attention stage) on a batch of three rooms, the whole pass through pipeline.scene_pass with
+    its streams - every integer tensor bit-identical to the oracle's pass, the last block's output within 1e-3."""
+    from stratified_transformer_amd import pipeline, scene
+    from util import oracle_scene_pass
+    cfg = pipeline.scannet_config()
+    xyz, offset = scene.make_batch([9000, 7000, 8000], seed=40, voxel=0.02)
+    states, results = pipeline.scene_pass(dev(xyz), dev(offset), cfg, seed=7)
+    torch.cuda.synchronize()
+    want = oracle_scene_pass(xyz, offset, cfg, states)
+    assert len(results) == len(want) == 4
+    for r, w in zip(results, want):
+        assert r["stage"] == w["stage"] and r["n"] == w["n"]
+        np.testing.assert_array_equal(_np(r["downsample_idx"]), w["downsample_idx"])
+        for name, par in (("even", 0), ("odd", 1)):
+            for field in ("index_1", "offsets", "rel_idx"):
+                np.testing.assert_array_equal(_np(getattr(r[name], field)), w["blocks"][par][field].numpy(), err_msg=f"stage {r['stage']} {name} {field}")
+        if "transition_knn" in w:
+            np.testing.assert_array_equal(_np(r["transition_knn"]), w["transition_knn"])
+        np.testing.assert_allclose(_np(r["out"]), w["out"], rtol=1e-3, atol=1e-3)

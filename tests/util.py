@@ -63,3 +63,44 @@ def random_csr_problem(n, seed, h, d, L, mean_len=12, max_len=None, empty_frac=0
 
 def dev(a, device="cuda"):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def oracle_scene_pass(xyz, offset, cfg, states):
+    """The oracle's restatement of pipeline.scene_pass (numpy/CPU): per stage the stratified FPS, both block
+    patterns, the last block's attention output, TransitionDown FPS + kNN.  `states` are the GPU pass's resident
+    synthetic tensors (q/k/v/tables/grad_out), copied to the host.  Returns a list of per-stage dicts."""
+    from oracle import index_ref, pointops_ref as ref
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    offset = np.asarray(offset, np.int32)
+    out = []
+    first = 0 if cfg.stem_transformer else 1
+
+    def transition(xyz, offset):
+        n_offset = np.asarray(index_ref.transition_down_offset(offset, cfg.ratio), np.int32)
+        idx = ref.furthestsampling(xyz, offset, n_offset)
+        n_xyz = np.ascontiguousarray(xyz[idx])
+        kidx, _ = ref.knnquery(cfg.k, xyz, n_xyz, offset, n_offset)
+        return n_xyz, n_offset, idx, kidx
+
+    if not cfg.stem_transformer:
+        xyz, offset, _, _ = transition(xyz, offset)
+    for si in range(first, len(cfg.stages)):
+        st, state = cfg.stages[si], states[si - first]
+        new_offset = np.asarray(index_ref.stratified_new_offset(offset, cfg.downsample_scale), np.int32)
+        ds = ref.furthestsampling(xyz, offset, new_offset)
+        x_t = torch.from_numpy(xyz)
+        blocks = [index_ref.build_stage_indices(x_t, offset, st.window_size, st.quant_size, torch.from_numpy(ds), par, "cuda") for par in (0, 1)]
+        q, k, v = (t.detach().cpu().numpy() for t in (state.q, state.k, state.v))
+        tq, tk, tv = (t.detach().cpu().numpy() for t in state.tables)
+        L = tq.shape[0]
+        blk = blocks[(st.depth - 1) % 2]
+        i1, offs = blk["index_1"].numpy().astype(np.int32), blk["offsets"].numpy().astype(np.int32)
+        rel = np.clip(blk["rel_idx"].numpy(), 0, L - 1).astype(np.int32)
+        sm = ref.segment_softmax(ref.attention_step1_v2(q, k, i1, offs) + ref.dot_prod_with_idx_v3(q, offs, k, i1, tq, tk, rel), offs)
+        att = ref.attention_step2_with_rel_pos_value_v2(sm, v, offs, i1, tv, rel)
+        row = dict(stage=si, n=xyz.shape[0], downsample_idx=ds, blocks=blocks, out=att)
+        if si < len(cfg.stages) - 1:
+            xyz, offset, _, kidx = transition(xyz, offset)
+            row["transition_knn"] = kidx
+        out.append(row)
+    return out

@@ -123,10 +123,16 @@ def check_tensor(t, dtype, name):
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def call(name, *args, device=None):
     """Launch `name` on torch's current stream of `device` and surface library errors."""
     l = lib()
-    stream = torch.cuda.current_stream(device).cuda_stream
+    if _raw_stream is not None and device is not None and device.index is not None:
+        stream = _raw_stream(device.index)  # the raw hipStream_t, without building a torch.cuda.Stream object
+    else:
+        stream = torch.cuda.current_stream(device).cuda_stream
     l.pointops2_set_stream(stream)
     getattr(l, name)(*args)
     err = l.pointops2_last_error()

@@ -100,8 +100,11 @@ class _with_csc:
             l.pointops2_set_key_rows(self.csc.n_keys)  # rows of k / v (may differ from the CSR's query rows)
 
     def __exit__(self, *exc):
-        _lib.lib().pointops2_set_csc(None, None, None)
-        _lib.lib().pointops2_set_key_rows(0)
+        # always undone: a launcher called later through the plain reference API must not see a stale view
+        if self.csc is not None:
+            l = _lib.lib()
+            l.pointops2_set_csc(None, None, None)
+            l.pointops2_set_key_rows(0)
 
 
 # ---------------------------------------------------------------------------------------------

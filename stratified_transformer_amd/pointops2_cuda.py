@@ -25,8 +25,11 @@ def _chk(*pairs):
 
 
 def _call(name, ref, *args):
-    with torch.cuda.device(ref.device):
+    if ref.device.index == torch.cuda.current_device():  # the usual case: no device switch, no guard object
         _lib.call(name, *args, device=ref.device)
+    else:
+        with torch.cuda.device(ref.device):
+            _lib.call(name, *args, device=ref.device)
 
 
 def _rows(table):

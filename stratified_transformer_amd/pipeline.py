@@ -277,13 +277,20 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
         state = states[si - first]
         state.xyz, state.offset = x, off
         out = None
+        # the next stage's index build stops the host twice; it is issued where the host can afford to wait:
+        # behind ALL blocks of the first stage (its samples only arrive when the stage-0 sampler is through),
+        # behind the FIRST block of a later stage (its samples are long there, and the late stages' blocks are
+        # short enough for the launches to fall behind otherwise)
+        early = si + 1 in stages and si > first
         for b in range(st.depth):
             out = attention_block(state, even if b % 2 == 0 else odd, timer)
+            if early and b == 0:
+                index(si + 1)
         results.append(dict(stage=si, n=x.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),
                             even=even, odd=odd, downsample_idx=ds, out=out))
         if knn_idx is not None:
             results[-1]["transition_knn"] = knn_idx
-        if si + 1 in stages:
+        if si + 1 in stages and not early:
             index(si + 1)
     if overlap:
         main.wait_stream(geo)

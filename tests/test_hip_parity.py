@@ -550,3 +550,52 @@ def test_scene_pass_scannet_config_three_rooms(P):
         if "transition_knn" in w:
             np.testing.assert_array_equal(_np(r["transition_knn"]), w["transition_knn"])
         np.testing.assert_allclose(_np(r["out"]), w["out"], rtol=1e-3, atol=1e-3)
+
+
+def test_full_size_batch_of_ten_rooms_properties(P):
+    """BASELINE config 5 at full size (10 rooms x 100 000 points in one batch, > 1 M points): too large for the oracle,
+    so the pass is checked through size-independent properties - every room of the batch gives exactly what it
+    gives alone (FPS indices, pair lists, rel-pos indices, attention output), CSR invariants, softmax rows."""
+    from stratified_transformer_amd import pipeline, scene
+    cfg = pipeline.s3dis_config()
+    cfg.stages = cfg.stages[:2]  # stage 0 at full size + the first TransitionDown / stage 1
+    sizes = [100000] * 10
+    xyz, offset = scene.make_batch(sizes, seed=70)
+    states, results = pipeline.scene_pass(dev(xyz), dev(offset), cfg, seed=3)
+    torch.cuda.synchronize()
+    r0 = results[0]
+    N, M = r0["n"], r0["M_even"]
+    assert N == 1000000 and M > 40 * N
+    offs, i1 = _np(r0["even"].offsets).astype(np.int64), _np(r0["even"].index_1)
+    assert offs[0] == 0 and offs[-1] == M and (np.diff(offs) > 0).all()          # every point attends at least to itself
+    room_of = np.searchsorted(offset, np.arange(N), side="right")
+    assert (room_of[np.repeat(np.arange(N), np.diff(offs))] == room_of[i1]).all()   # windows never cross a batch element
+    ds = _np(r0["downsample_idx"])
+    assert len(np.unique(ds)) == len(ds)
+    # one room alone == its slice of the batch
+    b, lo, hi = 3, int(offset[2]), int(offset[3])
+    one_states, one = pipeline.scene_pass(dev(xyz[lo:hi]), dev(np.array([hi - lo], np.int32)), cfg, seed=3)
+    torch.cuda.synchronize()
+    s_lo = 3 * (100000 // 8 + 1)
+    np.testing.assert_array_equal(ds[s_lo:s_lo + 100000 // 8 + 1] - lo, _np(one[0]["downsample_idx"]))
+    p_lo, p_hi = offs[lo], offs[hi]
+    np.testing.assert_array_equal(i1[p_lo:p_hi] - lo, _np(one[0]["even"].index_1))
+    np.testing.assert_array_equal(_np(r0["even"].rel_idx)[p_lo:p_hi], _np(one[0]["even"].rel_idx))
+    np.testing.assert_array_equal(offs[lo:hi + 1] - p_lo, _np(one[0]["even"].offsets))
+    # stage 1 of the batch: the room's TransitionDown samples and kNN agree with the stand-alone run
+    t_lo = 3 * 25001
+    np.testing.assert_array_equal(_np(r0["transition_knn"])[t_lo:t_lo + 25001] - lo, _np(one[0]["transition_knn"]))
+    # the attention operators on the room's slice: same q/k/v rows -> same output rows (fp32, different launch geometry)
+    st = states[0]
+    blk = r0["even"]
+    sm = P.segment_softmax(P.attention_step1_v2(st.q, st.k, blk.index_1, blk.offsets, 0)
+                           + P.dot_prod_with_idx_v3(st.q, blk.offsets, 0, st.k, blk.index_1, st.tables[0], st.tables[1], blk.rel_idx), blk.offsets)
+    rows = torch.zeros(N, 3, device="cuda").index_add_(0, torch.repeat_interleave(torch.arange(N, device="cuda"), torch.from_numpy(np.diff(offs)).cuda()), sm)
+    np.testing.assert_allclose(_np(rows), 1.0, rtol=0, atol=2e-5)
+    out = P.attention_step2_with_rel_pos_value_v2(sm, st.v, blk.offsets, 0, blk.index_1, st.tables[2], blk.rel_idx)
+    ob = one[0]["even"]
+    q1, k1, v1 = (t[lo:hi].contiguous() for t in (st.q, st.k, st.v))
+    sm1 = P.segment_softmax(P.attention_step1_v2(q1, k1, ob.index_1, ob.offsets, 0)
+                            + P.dot_prod_with_idx_v3(q1, ob.offsets, 0, k1, ob.index_1, st.tables[0], st.tables[1], ob.rel_idx), ob.offsets)
+    out1 = P.attention_step2_with_rel_pos_value_v2(sm1, v1, ob.offsets, 0, ob.index_1, st.tables[2], ob.rel_idx)
+    np.testing.assert_allclose(_np(out)[lo:hi], _np(out1), rtol=1e-5, atol=1e-5)

@@ -216,6 +216,14 @@ void pointops2_pairs_fill_launcher(int N, const float *xyz, float window, float 
 /* expands CSR offsets to the per-pair query id (index_0) */
 void csr_expand_launcher(int N, int M, const int *offsets, int *index0);
 
+/* ---- optional fused path (no counterpart in the reference's launcher set) -----------------------
+ * attn[m,hh] = softmax over the query's pairs of (<q,k[j]> + <q,Tq(m)> + <k[j],Tk(m)>): A1 + A2 + add + A3 of
+ * WindowAttention.forward (model/stratified_transformer.py:183-205) in one kernel.  d = 16 only; needs
+ * pointops2_set_table_rows(L).  attn [M,h] is fully written (no zero-fill needed). */
+void window_logits_softmax_forward_launcher(int N, int M, int h, int hdim, const float *q, const int *index_q_offsets,
+                                             const float *k, const int *index_k, const float *table_q,
+                                             const float *table_k, const int *rel_idx, float *attn);
+
 #ifdef __cplusplus
 }
 #endif

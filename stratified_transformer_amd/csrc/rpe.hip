@@ -68,6 +68,124 @@ __global__ __launch_bounds__(768, 6) void a2_fwd_kernel(int N, int h, int L, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused logits + softmax (optional fast path; not part of the reference's operator set):
+//   attn[m, hh] = softmax over the query's pairs of ( <q, k[j]> + <q, Tq(m)> + <k[j], Tk(m)> )
+// = A1 + A2 + add + A3 in one walk: the key rows are gathered once instead of twice and three [M, h]
+// round trips disappear.  Every term is computed exactly as the separate operators compute it (same dot4 /
+// butterfly order, logit = a1 + a2, expf(x - max) / sum), so for h = 3 or 4 (the softmax operator then sums in the
+// same order) the result is bit-identical to the operator chain, otherwise equal up to the order of that sum.
+// A query's logits stay in registers (lane (p, c): head c of pair slot p, one register per wave pass) when it
+// has at most 16 * WL_MAXP pairs; longer rows park them in the output buffer instead.
+// ------------------------------------------------------------------------------------------------
+constexpr int WL_MAXP = 8;
+
+template <int HG>
+__global__ __launch_bounds__(768, 6) void wlogit_softmax_kernel(int N, int h, int L, const float *__restrict__ q,
+                                                                const int *__restrict__ offs, const float *__restrict__ k,
+                                                                const int *__restrict__ idx_k, const float *__restrict__ table_q,
+                                                                const float *__restrict__ table_k, const int *__restrict__ rel,
+                                                                float *__restrict__ attn) {
+    constexpr int D = 16;
+    P2_WALK_PROLOGUE
+    float *Tq = lds, *Tk = lds + tsz;
+    stage_table<D>(Tq, table_q, L, h, h0, hgn);
+    stage_table<D>(Tk, table_k, L, h, h0, hgn);
+    __syncthreads();
+    const int wpb = blockDim.x >> 6;
+    // max / sum over the pair slots of a head: lanes that differ in the bits above LPG
+    auto slots_max = [&](float v) {
+        for (int st = LPG; st < 64; st <<= 1) v = fmaxf(v, __shfl_xor(v, st, 64));
+        return v;
+    };
+    auto slots_sum = [&](float v) {
+        for (int st = LPG; st < 64; st <<= 1) v += __shfl_xor(v, st, 64);
+        return v;
+    };
+    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
+        float4 q4[HG];
+#pragma unroll
+        for (int t = 0; t < HG; t++)
+            q4[t] = t < hgn ? ldg4(q + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
+        const int s = offs[qi], e = offs[qi + 1];
+        if (e <= s) continue;
+        const int np = (e - s + PPW - 1) / PPW;
+        // logit of head c (lane c of the pair's lane group keeps it) for pair m
+        auto logit = [&](int m, bool valid) -> float {
+            const int mm = valid ? m : s;
+            const int j = idx_k[mm];
+            const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+            float keep = 0.f;
+#pragma unroll
+            for (int t = 0; t < HG; t++) {
+                if (t < hgn) {
+                    const float4 k4 = ldg4(k + (size_t)j * C + (h0 + t) * D + 4 * c);
+                    const float a1 = xor_sum<1, LPG>(dot4(q4[t], k4));
+                    const float a2 = xor_sum<1, LPG>(dot4(q4[t], tsum<D>(Tq, L, t, r0, r1, r2, c)) + dot4(k4, tsum<D>(Tk, L, t, r0, r1, r2, c)));
+                    if (c == t) keep = a1 + a2;
+                }
+            }
+            return keep;
+        };
+        const bool mine = c < hgn;
+        if (np <= WL_MAXP) {
+            float lg[WL_MAXP];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < WL_MAXP; i++) {
+                lg[i] = -INFINITY;
+                if (i < np) {  // wave-uniform
+                    const int m = s + i * PPW + p;
+                    const float v = logit(m, m < e);
+                    if (m < e && mine) lg[i] = v;
+                    mx = fmaxf(mx, lg[i]);
+                }
+            }
+            mx = slots_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < WL_MAXP; i++) {
+                if (i < np) {
+                    const int m = s + i * PPW + p;
+                    if (m < e && mine) {
+                        lg[i] = expf(lg[i] - mx);
+                        sum += lg[i];
+                    }
+                }
+            }
+            sum = slots_sum(sum);
+#pragma unroll
+            for (int i = 0; i < WL_MAXP; i++) {
+                if (i < np) {
+                    const int m = s + i * PPW + p;
+                    if (m < e && mine) attn[(size_t)m * h + h0 + c] = lg[i] / sum;
+                }
+            }
+        } else {
+            float mx = -INFINITY;
+            for (int m0 = s; m0 < e; m0 += PPW) {
+                const int m = m0 + p;
+                const float v = logit(m, m < e);
+                if (m < e && mine) {
+                    attn[(size_t)m * h + h0 + c] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = slots_max(mx);
+            float sum = 0.f;
+            for (int m = s + p; m < e; m += PPW)
+                if (mine) {
+                    const float ex = expf(attn[(size_t)m * h + h0 + c] - mx);  // written by this very lane above
+                    attn[(size_t)m * h + h0 + c] = ex;
+                    sum += ex;
+                }
+            sum = slots_sum(sum);
+            for (int m = s + p; m < e; m += PPW)
+                if (mine) attn[(size_t)m * h + h0 + c] = attn[(size_t)m * h + h0 + c] / sum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // A2 backward, by query: grad_q (stored), grad_table_q (LDS -> atomics).
 // KEYSIDE: also grad_k (global atomics) and grad_table_k — the no-CSC fallback.
 // ------------------------------------------------------------------------------------------------
@@ -458,6 +576,22 @@ void dot_prod_with_idx_forward_cuda_launcher_v3(int N, int M, int h, int hdim, i
                            N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output);
     })
     else { set_error("d != 16 and d != 32"); return; }
+    check_launch();
+}
+
+void window_logits_softmax_forward_launcher(int N, int M, int h, int hdim, const float *q, const int *index_q_offsets,
+                                             const float *k, const int *index_k, const float *table_q, const float *table_k,
+                                             const int *rel_idx, float *attn) {
+    if (N <= 0 || M <= 0) return;
+    const int L = table_rows_or_error();
+    if (L <= 0) return;
+    if (hdim != 16) { set_error("window_logits_softmax: d != 16"); return; }
+    hipStream_t st = state().stream;
+    P2_LAUNCH_HG(16, 2, {
+        allow_big_lds(wlogit_softmax_kernel<HGc>, lds_bytes);
+        hipLaunchKernelGGL((wlogit_softmax_kernel<HGc>), dim3(persistent_blocks(N, ngroups, 12, 2), ngroups), dim3(768), lds_bytes, st,
+                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, attn);
+    })
     check_launch();
 }
 

@@ -1,0 +1,84 @@
+"""Optional fused fast path of WindowAttention.forward's operator sequence.
+
+The reference model calls five operators per attention block
+(model/stratified_transformer.py:183-208: attention_step1_v2, dot_prod_with_idx_v3, `+`, scatter_softmax,
+attention_step2_with_rel_pos_value_v2).  `window_attention` below is ONE autograd function for the whole
+sequence.  It is an addition, not a replacement: the model file runs unmodified on the operator API without
+it; a caller that owns its attention module can call it instead and gets
+
+  * forward: logits + softmax in one kernel (`window_logits_softmax_forward_launcher`: the key rows are
+    gathered once instead of twice, the three [M, h] intermediates a1, a2, a1+a2 never exist), then the
+    A4 kernel; only the softmax output [M, h] is kept for the backward;
+  * backward: the operators' own backward launchers, called in the order autograd would call them, with one
+    Python-level node instead of five;
+  * the same numbers: every term is computed as the separate operators compute it (bit-identical for
+    h = 3 or 4 heads, equal up to the order of the softmax sum otherwise).
+
+d = 16 only (the shipped configs); other head dims: use the operators.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from . import pointops as P
+from . import pointops2_cuda as pointops_cuda
+from ._lib import ptr
+
+
+class WindowAttention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, table_q, table_k, table_v, index0_offsets, index1, rel_idx):
+        for t in (q, k, v, table_q, table_k, table_v, index0_offsets, index1, rel_idx):
+            assert t.is_contiguous()
+        N, h, hdim = q.shape
+        if hdim != 16:
+            raise RuntimeError("window_attention: d != 16 (use the operators of pointops for other head dims)")
+        M = index1.shape[0]
+        L = table_q.shape[0]
+        assert table_k.shape[0] == L and table_v.shape[0] == L
+        pointops_cuda._chk((q, torch.float32, "q"), (k, torch.float32, "k"), (v, torch.float32, "v"),
+                           (table_q, torch.float32, "table_q"), (table_k, torch.float32, "table_k"), (table_v, torch.float32, "table_v"),
+                           (index0_offsets, torch.int32, "index0_offsets"), (index1, torch.int32, "index1"), (rel_idx, torch.int32, "rel_idx"))
+        attn = torch.empty((M, h), dtype=torch.float32, device=q.device)
+        pointops_cuda._rows(table_q)
+        pointops_cuda._call("window_logits_softmax_forward_launcher", q, int(index0_offsets.shape[0]) - 1, M, h, hdim,
+                            ptr(q), ptr(index0_offsets), ptr(k), ptr(index1), ptr(table_q), ptr(table_k), ptr(rel_idx), ptr(attn))
+        out = torch.zeros((N, h, hdim), dtype=torch.float32, device=q.device)
+        pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, 0, attn, v, index0_offsets, index1, table_v, rel_idx, out)
+        ctx.save_for_backward(q, k, v, table_q, table_k, table_v, index0_offsets, index1, rel_idx, attn)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, table_q, table_k, table_v, offs, index1, rel_idx, attn = ctx.saved_tensors
+        N, h, hdim = q.shape
+        NK = k.shape[0]
+        M = index1.shape[0]
+        L = table_q.shape[0]
+        dev = q.device
+        grad_out = grad_out.contiguous()
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        with P._with_csc(P.csc_of(offs, index1, NK)):
+            # A4
+            grad_attn = torch.empty((M, h), dtype=torch.float32, device=dev)
+            grad_v, grad_tv = z(v.shape[0], h, hdim), z(L, h, hdim, 3)
+            pointops_cuda.attention_step2_with_rel_pos_value_backward_cuda_v2(N, M, h, hdim, 0, grad_out, offs, index1, attn, v, table_v, rel_idx,
+                                                                              grad_attn, grad_v, grad_tv)
+            # A3
+            grad_logit = torch.empty((M, h), dtype=torch.float32, device=dev)
+            pointops_cuda._call("segment_softmax_backward_launcher", attn, int(offs.shape[0]) - 1, M, h, ptr(attn), ptr(grad_attn), ptr(offs), ptr(grad_logit))
+            # A1 and A2 receive the same gradient; grad_k is accumulated by both into one buffer
+            gq1 = torch.empty((N, h, hdim), dtype=torch.float32, device=dev)
+            gq2 = torch.empty((N, h, hdim), dtype=torch.float32, device=dev)
+            grad_k = z(NK, h, hdim)
+            grad_tq, grad_tk = z(L, h, hdim, 3), z(L, h, hdim, 3)
+            pointops_cuda.attention_step1_backward_cuda_v2(int(offs.shape[0]) - 1, M, h, h * hdim, 0, grad_logit, offs, index1, q, k, gq1, grad_k)
+            pointops_cuda.dot_prod_with_idx_backward_cuda_v3(N, M, h, hdim, 0, grad_logit, q, offs, k, index1, table_q, table_k, rel_idx,
+                                                             gq2, grad_k, grad_tq, grad_tk)
+        return gq1.add_(gq2), grad_k, grad_v, grad_tq, grad_tk, grad_tv, None, None, None
+
+
+def window_attention(q, k, v, table_q, table_k, table_v, index0_offsets, index1, rel_idx):
+    """q, k, v [N, h, 16] f32 (q already scaled, as the model does at :181); tables [L, h, 16, 3]; the block's CSR
+    pair list (index0_offsets [N+1], index1 [M] i32) and rel_idx [M, 3] i32  ->  [N, h, 16]"""
+    return WindowAttention.apply(q, k, v, table_q, table_k, table_v, index0_offsets, index1, rel_idx)

@@ -109,12 +109,19 @@ def make_stage_state(xyz, offset, st, seed):
                       torch.randn(n, h, d, generator=g, device=xyz.device))
 
 
-def attention_block(state, blk, timer):
-    """WindowAttention.forward's op sequence (model/stratified_transformer.py:183-208) + its backward."""
+def attention_block(state, blk, timer, fused=False):
+    """WindowAttention.forward's op sequence (model/stratified_transformer.py:183-208) + its backward.
+    fused=True: the optional one-function fast path (fused.window_attention) instead of the five
+    operators; same numbers."""
     q, k, v = state.q, state.k, state.v
     tq, tk, tv = state.tables
     for t in (q, k, v, tq, tk, tv):
         t.grad = None
+    if fused:
+        from . import fused as F
+        out = timer.run("attn_fwd/fused", F.window_attention, q, k, v, tq, tk, tv, blk.offsets, blk.index_1, blk.rel_idx)
+        timer.run("attn_bwd", out.backward, state.grad_out)
+        return out
     a1 = timer.run("attn_fwd/A1", P.attention_step1_v2, q, k, blk.index_1, blk.offsets, blk.n_max)
     a2 = timer.run("attn_fwd/A2", P.dot_prod_with_idx_v3, q, blk.offsets, blk.n_max, k, blk.index_1, tq, tk, blk.rel_idx)
     s = timer.run("attn_fwd/add", torch.add, a1, a2)
@@ -143,7 +150,7 @@ def geometry_stream(device, which=0):
     return _GEO_STREAMS[key]
 
 
-def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True):
+def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False):
     """Runs the whole unit once.  `states` (list of StageState) carries the resident synthetic tensors;
     pass None on the first call to have them created (not timed by bench.py).  Returns (states, results).
 
@@ -283,7 +290,7 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
         # short enough for the launches to fall behind otherwise)
         early = si + 1 in stages and si > first
         for b in range(st.depth):
-            out = attention_block(state, even if b % 2 == 0 else odd, timer)
+            out = attention_block(state, even if b % 2 == 0 else odd, timer, fused)
             if early and b == 0:
                 index(si + 1)
         results.append(dict(stage=si, n=x.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),

@@ -599,3 +599,43 @@ def test_full_size_batch_of_ten_rooms_properties(P):
                             + P.dot_prod_with_idx_v3(q1, ob.offsets, 0, k1, ob.index_1, st.tables[0], st.tables[1], ob.rel_idx), ob.offsets)
     out1 = P.attention_step2_with_rel_pos_value_v2(sm1, v1, ob.offsets, 0, ob.index_1, st.tables[2], ob.rel_idx)
     np.testing.assert_allclose(_np(out)[lo:hi], _np(out1), rtol=1e-5, atol=1e-5)
+
+
+def _op_chain(P, p, q, k, v, tq, tk, tv, offs, i1, rel):
+    a1 = P.attention_step1_v2(q, k, i1, offs, 0)
+    a2 = P.dot_prod_with_idx_v3(q, offs, 0, k, i1, tq, tk, rel)
+    sm = P.segment_softmax(a1 + a2, offs)
+    return P.attention_step2_with_rel_pos_value_v2(sm, v, offs, 0, i1, tv, rel)
+
+
+@pytest.mark.parametrize("case", ["window_h3", "csr_h6", "csr_h12", "csr_h24_long_rows", "csr_h1"])
+def test_fused_window_attention_matches_the_operator_chain(P, case):
+    """stratified_transformer_amd.fused.window_attention == the five operators, forward and backward
+    (bit-identical output for h = 3 or 4, where the softmax sums run in the same order; gradients go through the same backward launchers)."""
+    from stratified_transformer_amd import fused
+    if case == "window_h3":
+        p = window_problem(4000, seed=2, h=3, d=16)
+    elif case == "csr_h24_long_rows":
+        p = random_csr_problem(300, seed=31, h=24, d=16, L=64, mean_len=30, max_len=1500, empty_frac=0.2)
+    else:
+        h = int(case.split("_h")[1])
+        p = random_csr_problem(900, seed=30 + h, h=h, d=16, L=80 if h == 6 else 64, mean_len=45)
+    offs, i1, rel = dev(p["offsets"]), dev(p["index_1"]), dev(p["rel_idx"])
+    go = dev(p["go_rows"])
+    leaves_a = [_leaf(p[x]) for x in ("q", "k", "v", "table_q", "table_k", "table_v")]
+    leaves_b = [_leaf(p[x]) for x in ("q", "k", "v", "table_q", "table_k", "table_v")]
+    out_a = _op_chain(P, p, *leaves_a, offs, i1, rel)
+    out_b = fused.window_attention(*leaves_b, offs, i1, rel)
+    if p["h"] in (3, 4):
+        np.testing.assert_array_equal(_np(out_b), _np(out_a))
+    else:
+        np.testing.assert_allclose(_np(out_b), _np(out_a), rtol=1e-5, atol=1e-5)
+    out_a.backward(go)
+    out_b.backward(go)
+    for a, b, name in zip(leaves_a, leaves_b, ("q", "k", "v", "table_q", "table_k", "table_v")):
+        np.testing.assert_allclose(_np(b.grad), _np(a.grad), rtol=2e-5, atol=2e-4, err_msg=name)
+    # and against the oracle
+    r = ref.segment_softmax(ref.attention_step1_v2(p["q"], p["k"], p["index_1"], p["offsets"])
+                            + ref.dot_prod_with_idx_v3(p["q"], p["offsets"], p["k"], p["index_1"], p["table_q"], p["table_k"], p["rel_idx"]), p["offsets"])
+    want = ref.attention_step2_with_rel_pos_value_v2(r, p["v"], p["offsets"], p["index_1"], p["table_v"], p["rel_idx"])
+    np.testing.assert_allclose(_np(out_b), want, rtol=2e-5, atol=1e-4)

@@ -114,10 +114,10 @@ def component_table(timer, steps):
     return comp
 
 
-def roofline(comp, run):
-    """dominant timed op -> achieved algorithmic GB/s of its kernel"""
+def roofline(comp, run, among=None):
+    """dominant timed op (optionally only among the ops whose name starts with `among`) -> achieved algorithmic GB/s"""
     cfg, results = run["cfg"], run["results"]
-    name = max(comp, key=lambda k: comp[k]["ms_per_step"])
+    name = max((k for k in comp if among is None or k.startswith(among)), key=lambda k: comp[k]["ms_per_step"])
     r0 = results[0]
     st0 = cfg.stages[0]
     info = dict(N=r0["n"], M=(r0["M_even"] + r0["M_odd"]) // 2, C=st0.channels, h=st0.num_heads)
@@ -266,6 +266,7 @@ def main():
             "fused_module": {"ms_per_step": round(run["fused_elapsed"] / args.steps * 1e3, 3),
                              "note": "same passes with stratified_transformer_amd.fused.window_attention (logits+softmax in one kernel, one autograd node) instead of the five operators; not the headline"},
             "roofline": roofline(comp, run),
+            "roofline_attention": roofline(comp, run, among="attn"),
             "components_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(comp.items())},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -224,6 +224,16 @@ void window_logits_softmax_forward_launcher(int N, int M, int h, int hdim, const
                                              const float *k, const int *index_k, const float *table_q,
                                              const float *table_k, const int *rel_idx, float *attn);
 
+/* Backward of the whole sequence for that module: grad_logit [M,h] (scratch/output, fully written), grad_q [N,h,16],
+ * grad_k / grad_v [rows of k, h, 16] fully written; the three table gradients [L,h,16,3] are ACCUMULATED (zero-fill them).
+ * attn = the forward's softmax output.  Needs pointops2_set_table_rows(L), pointops2_set_csc(...) and, when k / v have
+ * other rows than q, pointops2_set_key_rows. */
+void window_attention_backward_launcher(int N, int M, int h, int hdim, const float *grad_out, const float *q, const float *k,
+                                        const float *v, const float *attn, const int *index0_offsets, const int *index1,
+                                        const float *table_q, const float *table_k, const float *table_v,
+                                        const int *rel_idx, float *grad_logit, float *grad_q, float *grad_k, float *grad_v,
+                                        float *grad_table_q, float *grad_table_k, float *grad_table_v);
+
 #ifdef __cplusplus
 }
 #endif

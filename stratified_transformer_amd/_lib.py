@@ -53,6 +53,7 @@ SIGNATURES = {
     "attention_step2_with_rel_pos_value_backward_cuda_launcher_v2": [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "segment_softmax_forward_launcher": [I, I, I, P, P, P],
     "window_logits_softmax_forward_launcher": [I, I, I, I, P, P, P, P, P, P, P, P],
+    "window_attention_backward_launcher": [I, I, I, I] + [P] * 18,
     "segment_softmax_backward_launcher": [I, I, I, P, P, P, P],
     "csr_expand_launcher": [I, I, P, P],
     "pointops2_bbox_launcher": [I, P, P],

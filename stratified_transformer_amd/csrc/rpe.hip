@@ -595,6 +595,25 @@ void window_logits_softmax_forward_launcher(int N, int M, int h, int hdim, const
     check_launch();
 }
 
+void window_attention_backward_launcher(int N, int M, int h, int hdim, const float *grad_out, const float *q, const float *k,
+                                        const float *v, const float *attn, const int *index0_offsets, const int *index1,
+                                        const float *table_q, const float *table_k, const float *table_v, const int *rel_idx,
+                                        float *grad_logit, float *grad_q, float *grad_k, float *grad_v, float *grad_table_q,
+                                        float *grad_table_k, float *grad_table_v) {
+    if (N <= 0 || M <= 0) return;
+    const int L = table_rows_or_error();
+    if (L <= 0) return;
+    const LaunchState &ls = state();
+    const int NK = ls.key_rows > 0 ? ls.key_rows : N;
+    if (!wattn_bwd(N, NK, M, h, hdim, L, grad_out, q, k, v, attn, index0_offsets, index1, table_q, table_k, table_v, rel_idx,
+                   ls.csc_offsets, ls.csc_pair, ls.csc_query, grad_logit, grad_q, grad_k, grad_v, grad_table_q, grad_table_k,
+                   grad_table_v)) {
+        set_error("window_attention_backward: needs d = 16, L <= 80 and a key-major view (pointops2_set_csc)");
+        return;
+    }
+    check_launch();
+}
+
 void dot_prod_with_idx_backward_cuda_launcher_v3(int N, int M, int h, int hdim, int n_max, const float *grad_out,
                                                  const float *q, const int *index_q_offsets, const float *k,
                                                  const int *index_k, const float *table_q, const float *table_k,

@@ -327,6 +327,179 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused backward of the whole window attention (optional module).  Two walks instead of seven:
+//   wattn_bwd_query_kernel  per query:  grad_attn = <Tv + v[j], grad_out>,  softmax backward over the row,
+//                           grad_logit stored, grad_q = sum grad_logit * k[j]  +  sum grad_logit * Tq
+//   wattn_bwd_key_kernel    per key (CSC):  grad_k = sum grad_logit * q[i] + sum grad_logit * Tk,
+//                           grad_v = sum attn * grad_out[i]
+// plus the three table_grad launches.  Each sum is taken as the separate operators take it (same pair order,
+// same butterflies, the two parts of grad_q / grad_k reduced separately and added at the end).
+// ------------------------------------------------------------------------------------------------
+constexpr int WB_MAXP = 8;
+
+template <int HG>
+__global__ __launch_bounds__(512, 4) void wattn_bwd_query_kernel(int N, int h, int L, const float *__restrict__ go,
+                                                                 const int *__restrict__ offs, const int *__restrict__ idx1,
+                                                                 const float *__restrict__ attn, const float *__restrict__ v,
+                                                                 const float *__restrict__ k, const float *__restrict__ table_v,
+                                                                 const float *__restrict__ table_q, const int *__restrict__ rel,
+                                                                 float *__restrict__ grad_logit, float *__restrict__ grad_q) {
+    constexpr int D = 16;
+    P2_WALK_PROLOGUE
+    float *Tv = lds, *Tq = lds + tsz;
+    stage_table<D>(Tv, table_v, L, h, h0, hgn);
+    stage_table<D>(Tq, table_q, L, h, h0, hgn);
+    __syncthreads();
+    const int wpb = blockDim.x >> 6;
+    auto slots_sum = [&](float x) {
+        for (int st = LPG; st < 64; st <<= 1) x += __shfl_xor(x, st, 64);
+        return x;
+    };
+    const bool mine = c < hgn;
+    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
+        float4 g4[HG], acc1[HG], acc2[HG];
+#pragma unroll
+        for (int t = 0; t < HG; t++) {
+            g4[t] = t < hgn ? ldg4(go + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
+            acc1[t] = acc2[t] = make_float4(0, 0, 0, 0);
+        }
+        const int s = offs[qi], e = offs[qi + 1];
+        const int np = (e - s + PPW - 1) / PPW;
+        // grad_attn of head c (kept by lane c of the pair's lane group) for pair m
+        auto dattn = [&](int m, bool valid) -> float {
+            const int mm = valid ? m : s;
+            const int j = idx1[mm];
+            const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+            float keep = 0.f;
+#pragma unroll
+            for (int t = 0; t < HG; t++) {
+                if (t < hgn) {
+                    const float4 v4 = ldg4(v + (size_t)j * C + (h0 + t) * D + 4 * c);
+                    const float tot = xor_sum<1, LPG>(dot4(add4(tsum<D>(Tv, L, t, r0, r1, r2, c), v4), g4[t]));
+                    if (c == t) keep = tot;
+                }
+            }
+            return keep;
+        };
+        // grad_q contributions of pair m, whose grad_logit of head c sits in lane c of its lane group
+        auto accumulate = [&](int m, bool valid, float dl) {
+            const int mm = valid ? m : s;
+            const int j = idx1[mm];
+            const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+#pragma unroll
+            for (int t = 0; t < HG; t++) {
+                const float w = quad_bcast(dl, t);
+                if (t < hgn && valid) {
+                    acc1[t] = fma4(w, ldg4(k + (size_t)j * C + (h0 + t) * D + 4 * c), acc1[t]);
+                    acc2[t] = fma4(w, tsum<D>(Tq, L, t, r0, r1, r2, c), acc2[t]);
+                }
+            }
+        };
+        if (e > s && np <= WB_MAXP) {
+            float da[WB_MAXP], a[WB_MAXP];
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < WB_MAXP; i++) {
+                da[i] = a[i] = 0.f;
+                if (i < np) {  // wave-uniform
+                    const int m = s + i * PPW + p;
+                    const float x = dattn(m, m < e);
+                    if (m < e && mine) {
+                        da[i] = x;
+                        a[i] = attn[(size_t)m * h + h0 + c];
+                        dot = fmaf(a[i], da[i], dot);
+                    }
+                }
+            }
+            dot = slots_sum(dot);
+#pragma unroll
+            for (int i = 0; i < WB_MAXP; i++) {
+                if (i < np) {
+                    const int m = s + i * PPW + p;
+                    const float dl = a[i] * (da[i] - dot);
+                    if (m < e && mine) grad_logit[(size_t)m * h + h0 + c] = dl;
+                    accumulate(m, m < e, dl);
+                }
+            }
+        } else if (e > s) {
+            float dot = 0.f;
+            for (int m0 = s; m0 < e; m0 += PPW) {
+                const int m = m0 + p;
+                const float x = dattn(m, m < e);
+                if (m < e && mine) {
+                    grad_logit[(size_t)m * h + h0 + c] = x;  // parked: this very lane reads it back below
+                    dot = fmaf(attn[(size_t)m * h + h0 + c], x, dot);
+                }
+            }
+            dot = slots_sum(dot);
+            for (int m0 = s; m0 < e; m0 += PPW) {
+                const int m = m0 + p;
+                float dl = 0.f;
+                if (m < e && mine) {
+                    dl = attn[(size_t)m * h + h0 + c] * (grad_logit[(size_t)m * h + h0 + c] - dot);
+                    grad_logit[(size_t)m * h + h0 + c] = dl;
+                }
+                accumulate(m, m < e, dl);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HG; t++) {
+            if (t < hgn) {
+                const float4 t1 = xor_sum4<LPG, 64>(acc1[t]), t2 = xor_sum4<LPG, 64>(acc2[t]);
+                if (p == 0) stg4(grad_q + (size_t)qi * C + (h0 + t) * D + 4 * c, add4(t1, t2));
+            }
+        }
+    }
+}
+
+template <int HG>
+__global__ __launch_bounds__(512, 4) void wattn_bwd_key_kernel(int NK, int h, int L, const float *__restrict__ grad_logit,
+                                                               const float *__restrict__ attn, const float *__restrict__ go,
+                                                               const float *__restrict__ q, const int *__restrict__ csc_offs,
+                                                               const int *__restrict__ csc_pair, const int *__restrict__ csc_query,
+                                                               const float *__restrict__ table_k, const int *__restrict__ rel,
+                                                               float *__restrict__ grad_k, float *__restrict__ grad_v) {
+    constexpr int D = 16;
+    P2_WALK_PROLOGUE
+    float *Tk = lds;
+    stage_table<D>(Tk, table_k, L, h, h0, hgn);
+    __syncthreads();
+    const int wpb = blockDim.x >> 6;
+    for (int kj = blockIdx.x * wpb + wave; kj < NK; kj += gridDim.x * wpb) {
+        float4 a1[HG], a2[HG], av[HG];
+#pragma unroll
+        for (int t = 0; t < HG; t++) a1[t] = a2[t] = av[t] = make_float4(0, 0, 0, 0);
+        const int s = csc_offs[kj], e = csc_offs[kj + 1];
+        for (int m0 = s; m0 < e; m0 += PPW) {
+            const int slot = m0 + p;
+            if (slot < e) {
+                const int m = csc_pair[slot], i = csc_query[slot];
+                const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
+#pragma unroll
+                for (int t = 0; t < HG; t++) {
+                    if (t < hgn) {
+                        const float dl = grad_logit[(size_t)m * h + h0 + t], at = attn[(size_t)m * h + h0 + t];
+                        a1[t] = fma4(dl, ldg4(q + (size_t)i * C + (h0 + t) * D + 4 * c), a1[t]);
+                        a2[t] = fma4(dl, tsum<D>(Tk, L, t, r0, r1, r2, c), a2[t]);
+                        av[t] = fma4(at, ldg4(go + (size_t)i * C + (h0 + t) * D + 4 * c), av[t]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < HG; t++) {
+            if (t < hgn) {
+                const float4 t1 = xor_sum4<LPG, 64>(a1[t]), t2 = xor_sum4<LPG, 64>(a2[t]), tv = xor_sum4<LPG, 64>(av[t]);
+                if (p == 0) {
+                    stg4(grad_k + (size_t)kj * C + (h0 + t) * D + 4 * c, add4(t1, t2));
+                    stg4(grad_v + (size_t)kj * C + (h0 + t) * D + 4 * c, tv);
+                }
+            }
+        }
+    }
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------
 static int walk_blocks(int rows, int groups, int waves_per_block, int per_cu) {
     int want = div_up(rows, waves_per_block);
@@ -392,6 +565,42 @@ bool a4_bwd_mfma(int N, int h, int hdim, int L, const float *go, const int *offs
     });
     if (L <= 64) launch_table_grad<4>(N, h, L, attn, go, offs, nullptr, rel, grad_table, fj.lane(1));
     else launch_table_grad<5>(N, h, L, attn, go, offs, nullptr, rel, grad_table, fj.lane(1));
+    return true;
+}
+
+// the optional fused backward; every output is fully written except the three table gradients (accumulated)
+bool wattn_bwd(int N, int NK, int M, int h, int hdim, int L, const float *go, const float *q, const float *k, const float *v,
+               const float *attn, const int *offs, const int *idx1, const float *table_q, const float *table_k,
+               const float *table_v, const int *rel, const int *co, const int *cp, const int *cq, float *grad_logit,
+               float *grad_q, float *grad_k, float *grad_v, float *gtq, float *gtk, float *gtv) {
+    if (hdim != 16 || co == nullptr || L < 1 || L > 80) return false;
+    hipStream_t st = state().stream;
+    with_heads(h, [&](auto tag) {
+        constexpr int HG = decltype(tag)::value;
+        const int groups = div_up(h, HG);
+        const size_t lds2 = (size_t)2 * HG * 3 * L * 16 * sizeof(float);
+        allow_big_lds(wattn_bwd_query_kernel<HG>, lds2);
+        hipLaunchKernelGGL((wattn_bwd_query_kernel<HG>), dim3(walk_blocks(N, groups, 8, 2), groups), dim3(512), lds2, st,
+                           N, h, L, go, offs, idx1, attn, v, k, table_v, table_q, rel, grad_logit, grad_q);
+    });
+    // everything below only reads grad_logit: the key walk and the three table gradients are independent
+    ForkJoin fj(st, fork_worthwhile((int64_t)M * h));
+    with_heads(h, [&](auto tag) {
+        constexpr int HG = decltype(tag)::value;
+        const int groups = div_up(h, HG);
+        const size_t lds1 = (size_t)HG * 3 * L * 16 * sizeof(float);
+        hipLaunchKernelGGL((wattn_bwd_key_kernel<HG>), dim3(walk_blocks(NK, groups, 8, 2), groups), dim3(512), lds1, fj.lane(0),
+                           NK, h, L, grad_logit, attn, go, q, co, cp, cq, table_k, rel, grad_k, grad_v);
+    });
+    if (L <= 64) {
+        launch_table_grad<4>(NK, h, L, grad_logit, k, co, cp, rel, gtk, fj.lane(1));
+        launch_table_grad<4>(N, h, L, grad_logit, q, offs, nullptr, rel, gtq, fj.lane(2));
+        launch_table_grad<4>(N, h, L, attn, go, offs, nullptr, rel, gtv, fj.lane(3));
+    } else {
+        launch_table_grad<5>(NK, h, L, grad_logit, k, co, cp, rel, gtk, fj.lane(1));
+        launch_table_grad<5>(N, h, L, grad_logit, q, offs, nullptr, rel, gtq, fj.lane(2));
+        launch_table_grad<5>(N, h, L, attn, go, offs, nullptr, rel, gtv, fj.lane(3));
+    }
     return true;
 }
 

@@ -78,4 +78,9 @@ bool a2_bwd_mfma(int N, int NK, int M, int h, int hdim, int L, const float *go, 
 bool a4_bwd_mfma(int N, int h, int hdim, int L, const float *go, const int *offs, const int *idx1, const float *attn,
                  const float *v, const float *table, const int *rel, float *grad_attn, float *grad_table, ForkJoin &fj);
 
+bool wattn_bwd(int N, int NK, int M, int h, int hdim, int L, const float *go, const float *q, const float *k, const float *v,
+               const float *attn, const int *offs, const int *idx1, const float *table_q, const float *table_k,
+               const float *table_v, const int *rel, const int *co, const int *cp, const int *cq, float *grad_logit,
+               float *grad_q, float *grad_k, float *grad_v, float *gtq, float *gtk, float *gtv);
+
 }  // namespace p2

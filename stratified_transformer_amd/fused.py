@@ -9,8 +9,9 @@ it; a caller that owns its attention module can call it instead and gets
   * forward: logits + softmax in one kernel (`window_logits_softmax_forward_launcher`: the key rows are
     gathered once instead of twice, the three [M, h] intermediates a1, a2, a1+a2 never exist), then the
     A4 kernel; only the softmax output [M, h] is kept for the backward;
-  * backward: the operators' own backward launchers, called in the order autograd would call them, with one
-    Python-level node instead of five;
+  * backward: two walks over the pair list instead of seven (`window_attention_backward_launcher`: by query
+    grad_attn -> softmax backward -> grad_logit and grad_q; by key grad_k and grad_v) plus the three table
+    gradients; without a key-major view the operators' own backward launchers, in autograd's order;
   * the same numbers: every term is computed as the separate operators compute it (bit-identical for
     h = 3 or 4 heads, equal up to the order of the softmax sum otherwise).
 
@@ -58,18 +59,29 @@ class WindowAttention(Function):
         dev = q.device
         grad_out = grad_out.contiguous()
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
-        with P._with_csc(P.csc_of(offs, index1, NK)):
-            # A4
-            grad_attn = torch.empty((M, h), dtype=torch.float32, device=dev)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        csc = P.csc_of(offs, index1, NK)
+        if csc is not None and L <= 80:
+            # two walks (by query, by key) + the three table gradients: DESIGN.md 4.5
+            grad_logit, grad_q, grad_k, grad_v = e(M, h), e(N, h, hdim), e(NK, h, hdim), e(v.shape[0], h, hdim)
+            grad_tq, grad_tk, grad_tv = z(L, h, hdim, 3), z(L, h, hdim, 3), z(L, h, hdim, 3)
+            pointops_cuda._chk((grad_out, torch.float32, "grad_out"))
+            pointops_cuda._rows(table_q)
+            with P._with_csc(csc):
+                pointops_cuda._call("window_attention_backward_launcher", q, int(offs.shape[0]) - 1, M, h, hdim, ptr(grad_out), ptr(q), ptr(k),
+                                    ptr(v), ptr(attn), ptr(offs), ptr(index1), ptr(table_q), ptr(table_k), ptr(table_v), ptr(rel_idx),
+                                    ptr(grad_logit), ptr(grad_q), ptr(grad_k), ptr(grad_v), ptr(grad_tq), ptr(grad_tk), ptr(grad_tv))
+            return grad_q, grad_k, grad_v, grad_tq, grad_tk, grad_tv, None, None, None
+        with P._with_csc(csc):
+            # the operators' own backward launchers, in autograd's order
+            grad_attn = e(M, h)
             grad_v, grad_tv = z(v.shape[0], h, hdim), z(L, h, hdim, 3)
             pointops_cuda.attention_step2_with_rel_pos_value_backward_cuda_v2(N, M, h, hdim, 0, grad_out, offs, index1, attn, v, table_v, rel_idx,
                                                                               grad_attn, grad_v, grad_tv)
-            # A3
-            grad_logit = torch.empty((M, h), dtype=torch.float32, device=dev)
+            grad_logit = e(M, h)
             pointops_cuda._call("segment_softmax_backward_launcher", attn, int(offs.shape[0]) - 1, M, h, ptr(attn), ptr(grad_attn), ptr(offs), ptr(grad_logit))
             # A1 and A2 receive the same gradient; grad_k is accumulated by both into one buffer
-            gq1 = torch.empty((N, h, hdim), dtype=torch.float32, device=dev)
-            gq2 = torch.empty((N, h, hdim), dtype=torch.float32, device=dev)
+            gq1, gq2 = e(N, h, hdim), e(N, h, hdim)
             grad_k = z(NK, h, hdim)
             grad_tq, grad_tk = z(L, h, hdim, 3), z(L, h, hdim, 3)
             pointops_cuda.attention_step1_backward_cuda_v2(int(offs.shape[0]) - 1, M, h, h * hdim, 0, grad_logit, offs, index1, q, k, gq1, grad_k)

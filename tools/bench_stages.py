@@ -47,7 +47,13 @@ def main():
         res['A2b'] = timeit(lambda: bwd(a2, g_pairs))
         res['A3b'] = timeit(lambda: bwd(sm, g_pairs))
         res['A4b'] = timeit(lambda: bwd(out, s.grad_out))
+        from stratified_transformer_amd import fused
+        fo = fused.window_attention(q, k, v, tq, tk, tv, b.offsets, b.index_1, b.rel_idx)
+        fwd_sum, bwd_sum = sum(v_ for k_, v_ in res.items() if k_.endswith('f')), sum(v_ for k_, v_ in res.items() if k_.endswith('b'))
         tot = sum(res.values())
+        res['FUSEDf'] = timeit(lambda: fused.window_attention(q, k, v, tq, tk, tv, b.offsets, b.index_1, b.rel_idx))
+        res['FUSEDb'] = timeit(lambda: bwd(fo, s.grad_out))
+        res['ops_f'], res['ops_b'] = fwd_sum, bwd_sum
         print('stage', si, 'N', s.xyz.shape[0], 'M', M, 'h', st.num_heads, 'L', tq.shape[0], 'depth', st.depth,
               {k_: round(v_) for k_, v_ in res.items()}, 'block us', round(tot), 'stage ms', round(tot * st.depth / 1e3, 2))
         for k_, v_ in res.items():

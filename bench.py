@@ -264,7 +264,7 @@ def main():
                        "stage_points": [r["n"] for r in run["results"]], "parallelism": "1 scene per rank, no data-path collective"},
             "overlap": "sampling chain, kNN and the next stage's index build on side streams beside the attention blocks; components_ms_per_step are per-op device times (fps/*: events inside the timed region; the others: the same passes repeated with events around every op) and overlap in wall time",
             "fused_module": {"ms_per_step": round(run["fused_elapsed"] / args.steps * 1e3, 3),
-                             "note": "same passes with stratified_transformer_amd.fused.window_attention (logits+softmax in one kernel, one autograd node) instead of the five operators; not the headline"},
+                             "note": "same passes with stratified_transformer_amd.fused.window_attention (fused logits+softmax forward, two-walk backward, one autograd node) instead of the five operators; not the headline"},
             "roofline": roofline(comp, run),
             "roofline_attention": roofline(comp, run, among="attn"),
             "components_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(comp.items())},

@@ -330,7 +330,9 @@ __device__ __forceinline__ KeyMax wave_key_max_bf(unsigned long long v) {
     return r;
 }
 
-// STAMP: diagnostic build only (P2_FPS_STAMPS=1): per-wave cycle sums of the step phases -> dbg
+// STAMP: diagnostic build only (P2_FPS_STAMPS=1): per-wave cycle sums of the step phases -> dbg; P2_FPS_TRACE=file
+// also dumps the absolute phase times of every wave for FPS_TRACE_STEPS steps (tools/fps_trace.py)
+constexpr int FPS_TRACE_STEPS = 512;
 template <int NBL, int NW, bool STAMP = false>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
                                                              const int *__restrict__ offset, const int *__restrict__ new_offset,
@@ -432,7 +434,11 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
     };
 
     for (int j = start_m + max(done, 1); j < end_m; j++) {
+        const bool trace = STAMP && dbg && (j - start_m) >= 5000 && (j - start_m) < 5000 + FPS_TRACE_STEPS;
+        unsigned long long *tr = nullptr;
+        if (trace) tr = dbg + 16 * 8 + ((size_t)(j - start_m - 5000) * NW + wave) * 8;
         if (STAMP) t_a = __builtin_amdgcn_s_memtime();
+        if (trace && lane == 0) tr[0] = t_a;
         unsigned long long hm[NBL];
         unsigned long long any = 0ull;
         int ntouched = 0;
@@ -446,6 +452,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             ntouched += __popcll(hm[s]);
         }
         if (STAMP) n_upd += ntouched;
+        if (trace && lane == 0) { tr[1] = __builtin_amdgcn_s_memtime(); tr[7] = ntouched; }
         if (ntouched == 1 && BSZ == 64) {
             // the common case: exactly one owned bucket to update, straight-line
             int code = -1;
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             }
         }
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_test += t_b - t_a; t_a = t_b; }
+        if (trace && lane == 0) tr[2] = t_b;
         if (recompute) {  // wave-uniform
             unsigned long long mk = key[0];
             float mx_ = bx[0], my_ = by[0], mz_ = bz[0];
@@ -549,8 +557,10 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             }
         }
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_red += t_b - t_a; t_a = t_b; }
+        if (trace && lane == 0) tr[3] = t_b;
         lds_barrier();  // every wave's slot is current
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_bar += t_b - t_a; t_a = t_b; }
+        if (trace && lane == 0) tr[4] = t_b;
         if (wave == 0) {
             // arg-max over the NW slots (one wave, so the others do not compete for issue slots)
             const int src = lane < NW ? lane : 0;
@@ -577,12 +587,14 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
                 idx[j] = start_n + rel_of(gm.key, Bref, log2B);
             }
         }
+        if (trace && lane == 0) tr[5] = __builtin_amdgcn_s_memtime();
         lds_barrier();  // the new sample is published
         {
             const float4 ns = wbest[1][0];
             x1 = ns.x; y1 = ns.y; z1 = ns.z;
         }
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_fin += t_b - t_a; }
+        if (trace && lane == 0) tr[6] = t_b;
     }
     if (STAMP && dbg && lane == 0) {
         unsigned long long *o = dbg + (blockIdx.x * NW + wave) * 8;
@@ -670,10 +682,18 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
                        new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, DBG_)
     if (getenv("P2_FPS_STAMPS") && nbuckets > 1024) {  // diagnostic only: synchronous, prints phase shares to stderr
         unsigned long long *dbg = nullptr, host[16 * 8];
-        (void)hipMalloc(&dbg, sizeof(host) * b);
+        const size_t trace_words = (size_t)FPS_TRACE_STEPS * 16 * 8;
+        (void)hipMalloc(&dbg, (sizeof(host) + trace_words * 8) * b);
+        (void)hipMemset(dbg, 0, (sizeof(host) + trace_words * 8) * b);
         if (NWsel == 8) P2_FPS_LAUNCH(4, 8, true, dbg); else P2_FPS_LAUNCH(2, 16, true, dbg);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+        if (const char *tf = getenv("P2_FPS_TRACE")) {
+            unsigned long long *tbuf = (unsigned long long *)malloc(trace_words * 8);
+            (void)hipMemcpy(tbuf, dbg + 16 * 8, trace_words * 8, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(tf, "wb")) { fwrite(tbuf, 8, trace_words, f); fclose(f); }
+            free(tbuf);
+        }
         (void)hipFree(dbg);
         for (int w = 0; w < NWsel; w++)
             fprintf(stderr, "[fps stamps] wave %2d: test+update %llu reduce %llu barrier %llu final %llu | updates %llu | cycles %llu realtime(100MHz) %llu -> %.0f MHz\n",

@@ -426,10 +426,33 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
     int whold = -1;
     bool recompute = true;
 
+    // The owner lane (code & 63) of slot code >> 6 takes the bucket's new key and best point.  With 64-point buckets
+    // this is five v_writelane_b32 (lane select in m0) under a wave-uniform slot test; the generic form masks lanes.
+    // (On the step's critical path an instruction costs ~9 cycles, tools/fps_trace.py: count them.)
     auto update_regs = [&](int code, const KeyMax &km, float cx, float cy, float cz) {
+        if (BSZ == 64) {
+            const int ol = __builtin_amdgcn_readfirstlane(code & 63);
 #pragma unroll
-        for (int s = 0; s < NBL; s++)
-            if ((code >> 6) == s && lane == (code & 63)) { key[s] = km.key; bx[s] = cx; by[s] = cy; bz[s] = cz; }
+            for (int s = 0; s < NBL; s++)
+                if ((code >> 6) == s) {
+                    int lo = (int)(unsigned)key[s], hi = (int)(unsigned)(key[s] >> 32);
+                    int ix = __float_as_int(bx[s]), iy = __float_as_int(by[s]), iz = __float_as_int(bz[s]);
+                    asm volatile("s_mov_b32 m0, %10\n\t"
+                                 "v_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\tv_writelane_b32 %2, %7, m0\n\t"
+                                 "v_writelane_b32 %3, %8, m0\n\tv_writelane_b32 %4, %9, m0"
+                                 : "+v"(lo), "+v"(hi), "+v"(ix), "+v"(iy), "+v"(iz)
+                                 : "s"((int)(unsigned)km.key), "s"((int)(unsigned)(km.key >> 32)),
+                                   "s"(__builtin_amdgcn_readfirstlane(__float_as_int(cx))), "s"(__builtin_amdgcn_readfirstlane(__float_as_int(cy))),
+                                   "s"(__builtin_amdgcn_readfirstlane(__float_as_int(cz))), "s"(ol)
+                                 : "m0");
+                    key[s] = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+                    bx[s] = __int_as_float(ix); by[s] = __int_as_float(iy); bz[s] = __int_as_float(iz);
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NBL; s++)
+                if ((code >> 6) == s && lane == (code & 63)) { key[s] = km.key; bx[s] = cx; by[s] = cy; bz[s] = cz; }
+        }
         if (code == whold) recompute = true;
     };
 
@@ -459,17 +482,15 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
 #pragma unroll
             for (int s = 0; s < NBL; s++)
                 if (hm[s]) code = s * 64 + __ffsll(hm[s]) - 1;
-            const int pos = start_n + (code * NW + wave) * 64 + lane;
-            unsigned long long k = 0ull;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pos < end_n) {
-                p = pts[pos];
-                const unsigned rk = rank[pos];
-                const float d = sqd(p.x - x1, p.y - y1, p.z - z1);
-                const float d2 = fminf(d, p.w);
-                if (d2 != p.w) reinterpret_cast<float *>(pts + pos)[3] = d2;
-                k = ((unsigned long long)__float_as_uint(d2) << 32) | rk;
-            }
+            // straight-line: lanes past the end of the cloud work on a copy of its last point (they can only tie with
+            // that point itself), and the distance is stored whether it changed or not
+            code = __builtin_amdgcn_readfirstlane(code);
+            const int pos = min(start_n + (code * NW + wave) * 64 + lane, end_n - 1);
+            const float4 p = pts[pos];
+            const unsigned rk = rank[pos];
+            const float d2 = fminf(sqd(p.x - x1, p.y - y1, p.z - z1), p.w);
+            reinterpret_cast<float *>(pts + pos)[3] = d2;
+            const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | rk;
             const KeyMax km = wave_key_max(k);
             update_regs(code, km, rl(p.x, km.lane), rl(p.y, km.lane), rl(p.z, km.lane));
             any = 0ull;

@@ -580,6 +580,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_red += t_b - t_a; t_a = t_b; }
         if (trace && lane == 0) tr[3] = t_b;
         lds_barrier();  // every wave's slot is current
+        unsigned long long win_key = 0ull;
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_bar += t_b - t_a; t_a = t_b; }
         if (trace && lane == 0) tr[4] = t_b;
         if (wave == 0) {
@@ -603,10 +604,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             } else {
                 gm = wave_key_max(gk);
             }
-            if (lane == 0) {
-                wbest[1][0] = make_float4(rl(gc.x, gm.lane), rl(gc.y, gm.lane), rl(gc.z, gm.lane), 0.f);
-                idx[j] = start_n + rel_of(gm.key, Bref, log2B);
-            }
+            if (lane == 0) wbest[1][0] = make_float4(rl(gc.x, gm.lane), rl(gc.y, gm.lane), rl(gc.z, gm.lane), 0.f);
+            win_key = gm.key;
         }
         if (trace && lane == 0) tr[5] = __builtin_amdgcn_s_memtime();
         lds_barrier();  // the new sample is published
@@ -614,6 +613,9 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             const float4 ns = wbest[1][0];
             x1 = ns.x; y1 = ns.y; z1 = ns.z;
         }
+        // the sample's index (key -> position, a dozen instructions and a store) is nobody's input: it is written
+        // behind the barrier, off the path the 15 other waves wait on
+        if (wave == 0 && lane == 0) idx[j] = start_n + rel_of(win_key, Bref, log2B);
         if (STAMP) { t_b = __builtin_amdgcn_s_memtime(); c_fin += t_b - t_a; }
         if (trace && lane == 0) tr[6] = t_b;
     }

@@ -512,29 +512,23 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
 #pragma unroll
             for (int s = 0; s < NBL; s++) any |= hm[s];
             if (BSZ == 64) {
-                // all loads first (kept in flight together), then one reduction per touched bucket
+                // all loads first (kept in flight together), then one reduction per touched bucket; straight-line
+                // per bucket like the single-bucket path (clamped lanes, distance stored unconditionally)
                 float4 p[4];
                 unsigned rk[4];
-                bool ok[4];
+                int pos[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int pos = start_n + (max(code[u], 0) * NW + wave) * 64 + lane;
-                    ok[u] = code[u] >= 0 && pos < end_n;
-                    p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    rk[u] = 0u;
-                    if (ok[u]) { p[u] = pts[pos]; rk[u] = rank[pos]; }
+                    code[u] = __builtin_amdgcn_readfirstlane(code[u]);
+                    pos[u] = min(start_n + (max(code[u], 0) * NW + wave) * 64 + lane, end_n - 1);
+                    if (code[u] >= 0) { p[u] = pts[pos[u]]; rk[u] = rank[pos[u]]; }  // wave-uniform
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (code[u] < 0) continue;  // wave-uniform: absent entries cost nothing
-                    unsigned long long k = 0ull;
-                    if (ok[u]) {
-                        const float d = sqd(p[u].x - x1, p[u].y - y1, p[u].z - z1);
-                        const float d2 = fminf(d, p[u].w);
-                        if (d2 != p[u].w) reinterpret_cast<float *>(pts + start_n + (code[u] * NW + wave) * 64 + lane)[3] = d2;
-                        k = ((unsigned long long)__float_as_uint(d2) << 32) | rk[u];
-                    }
-                    const KeyMax km = wave_key_max(k);
+                    const float d2 = fminf(sqd(p[u].x - x1, p[u].y - y1, p[u].z - z1), p[u].w);
+                    reinterpret_cast<float *>(pts + pos[u])[3] = d2;
+                    const KeyMax km = wave_key_max(((unsigned long long)__float_as_uint(d2) << 32) | rk[u]);
                     update_regs(code[u], km, rl(p[u].x, km.lane), rl(p[u].y, km.lane), rl(p[u].z, km.lane));
                 }
             } else {

@@ -333,8 +333,8 @@ __device__ __forceinline__ KeyMax wave_key_max_bf(unsigned long long v) {
 // STAMP: diagnostic build only (P2_FPS_STAMPS=1): per-wave cycle sums of the step phases -> dbg; P2_FPS_TRACE=file
 // also dumps the absolute phase times of every wave for FPS_TRACE_STEPS steps (tools/fps_trace.py)
 constexpr int FPS_TRACE_STEPS = 512;
-template <int NBL, int NW, bool STAMP = false>
-__global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B, int BSZ, const float *__restrict__ xyz,
+template <int NBL, int NW, bool STAMP = false, bool B64 = false>
+__global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B, int BSZ_arg, const float *__restrict__ xyz,
                                                              const int *__restrict__ offset, const int *__restrict__ new_offset,
                                                              float4 *__restrict__ pts, const unsigned *__restrict__ rank,
                                                              const int *__restrict__ prev_idx, const int *__restrict__ prev_offset,
@@ -355,6 +355,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
         return;
     }
     const int n = end_n - start_n;
+    const int BSZ = B64 ? 64 : BSZ_arg;  // 64-point buckets (every cloud up to 131072 points) are a compile-time fact:
+                                         // the generic paths below then do not exist in the code
     const int nb = (n + BSZ - 1) / BSZ;
 
     // samples inherited from the previous call on this state
@@ -496,19 +498,23 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             any = 0ull;
         }
         while (any) {
-            // next (up to) four touched buckets across all slots: code = slot*64 + owner lane, -1 = none
+            // next (up to) four touched buckets across all slots: code = slot*64 + owner lane, -1 = none (scalar
+            // selects, no branches)
             int code[4];
-            any = 0ull;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                code[u] = -1;
+                int c = -1;
+                bool taken = false;
 #pragma unroll
-                for (int s = 0; s < NBL; s++)
-                    if (code[u] < 0 && hm[s]) {
-                        code[u] = s * 64 + __ffsll(hm[s]) - 1;
-                        hm[s] &= hm[s] - 1;
-                    }
+                for (int s = 0; s < NBL; s++) {
+                    const bool take = !taken && hm[s] != 0ull;
+                    c = take ? s * 64 + (int)__ffsll(hm[s]) - 1 : c;
+                    hm[s] = take ? (hm[s] & (hm[s] - 1)) : hm[s];
+                    taken = taken || take;
+                }
+                code[u] = c;
             }
+            any = 0ull;
 #pragma unroll
             for (int s = 0; s < NBL; s++) any |= hm[s];
             if (BSZ == 64) {
@@ -695,8 +701,14 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     const int NWsel = nw_env == 8 ? 8 : 16;
     const int per_lane = div_up(nbuckets, NWsel * 64);
 #define P2_FPS_LAUNCH(NBL_, NW_, STAMP_, DBG_)                                                                              \
-    hipLaunchKernelGGL((fps_bucket_kernel<NBL_, NW_, STAMP_>), dim3(b), dim3(NW_ * 64), 0, st, Bref, log2B, BSZ, xyz, offset, \
-                       new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, DBG_)
+    do {                                                                                                                    \
+        if (BSZ == 64)                                                                                                      \
+            hipLaunchKernelGGL((fps_bucket_kernel<NBL_, NW_, STAMP_, true>), dim3(b), dim3(NW_ * 64), 0, st, Bref, log2B, BSZ, xyz, \
+                               offset, new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, DBG_);            \
+        else                                                                                                                \
+            hipLaunchKernelGGL((fps_bucket_kernel<NBL_, NW_, STAMP_, false>), dim3(b), dim3(NW_ * 64), 0, st, Bref, log2B, BSZ, xyz, \
+                               offset, new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, DBG_);            \
+    } while (0)
     if (getenv("P2_FPS_STAMPS") && nbuckets > 1024) {  // diagnostic only: synchronous, prints phase shares to stderr
         unsigned long long *dbg = nullptr, host[16 * 8];
         const size_t trace_words = (size_t)FPS_TRACE_STEPS * 16 * 8;

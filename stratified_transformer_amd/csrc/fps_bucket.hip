@@ -497,6 +497,36 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             update_regs(code, km, rl(p.x, km.lane), rl(p.y, km.lane), rl(p.z, km.lane));
             any = 0ull;
         }
+        if (ntouched == 2 && B64) {
+            // two owned buckets (the busiest wave of most steps): both loads first, then the two reductions, no loop
+            int c2[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                int c = -1;
+                bool taken = false;
+#pragma unroll
+                for (int s = 0; s < NBL; s++) {
+                    const bool take = !taken && hm[s] != 0ull;
+                    c = take ? s * 64 + (int)__ffsll(hm[s]) - 1 : c;
+                    hm[s] = take ? (hm[s] & (hm[s] - 1)) : hm[s];
+                    taken = taken || take;
+                }
+                c2[u] = __builtin_amdgcn_readfirstlane(c);
+            }
+            const int pa = min(start_n + (c2[0] * NW + wave) * 64 + lane, end_n - 1);
+            const int pb = min(start_n + (c2[1] * NW + wave) * 64 + lane, end_n - 1);
+            const float4 qa = pts[pa], qb = pts[pb];
+            const unsigned ra = rank[pa], rb = rank[pb];
+            const float da = fminf(sqd(qa.x - x1, qa.y - y1, qa.z - z1), qa.w);
+            const float db = fminf(sqd(qb.x - x1, qb.y - y1, qb.z - z1), qb.w);
+            reinterpret_cast<float *>(pts + pa)[3] = da;
+            reinterpret_cast<float *>(pts + pb)[3] = db;
+            const KeyMax ka = wave_key_max(((unsigned long long)__float_as_uint(da) << 32) | ra);
+            update_regs(c2[0], ka, rl(qa.x, ka.lane), rl(qa.y, ka.lane), rl(qa.z, ka.lane));
+            const KeyMax kb = wave_key_max(((unsigned long long)__float_as_uint(db) << 32) | rb);
+            update_regs(c2[1], kb, rl(qb.x, kb.lane), rl(qb.y, kb.lane), rl(qb.z, kb.lane));
+            any = 0ull;
+        }
         while (any) {
             // next (up to) four touched buckets across all slots: code = slot*64 + owner lane, -1 = none (scalar
             // selects, no branches)

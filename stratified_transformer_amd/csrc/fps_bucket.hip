@@ -527,6 +527,40 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
             update_regs(c2[1], kb, rl(qb.x, kb.lane), rl(qb.y, kb.lane), rl(qb.z, kb.lane));
             any = 0ull;
         }
+        if (ntouched == 3 && B64) {
+            // three owned buckets: the same straight-line form
+            int c3[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                int c = -1;
+                bool taken = false;
+#pragma unroll
+                for (int s = 0; s < NBL; s++) {
+                    const bool take = !taken && hm[s] != 0ull;
+                    c = take ? s * 64 + (int)__ffsll(hm[s]) - 1 : c;
+                    hm[s] = take ? (hm[s] & (hm[s] - 1)) : hm[s];
+                    taken = taken || take;
+                }
+                c3[u] = __builtin_amdgcn_readfirstlane(c);
+            }
+            int pp[3];
+            float4 qq[3];
+            unsigned rr[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                pp[u] = min(start_n + (c3[u] * NW + wave) * 64 + lane, end_n - 1);
+                qq[u] = pts[pp[u]];
+                rr[u] = rank[pp[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const float d2 = fminf(sqd(qq[u].x - x1, qq[u].y - y1, qq[u].z - z1), qq[u].w);
+                reinterpret_cast<float *>(pts + pp[u])[3] = d2;
+                const KeyMax km = wave_key_max(((unsigned long long)__float_as_uint(d2) << 32) | rr[u]);
+                update_regs(c3[u], km, rl(qq[u].x, km.lane), rl(qq[u].y, km.lane), rl(qq[u].z, km.lane));
+            }
+            any = 0ull;
+        }
         while (any) {
             // next (up to) four touched buckets across all slots: code = slot*64 + owner lane, -1 = none (scalar
             // selects, no branches)

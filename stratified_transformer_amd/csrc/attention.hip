@@ -46,14 +46,14 @@ __global__ __launch_bounds__(256) void a1_fwd_kernel(int N, int h, const float *
         const float *krow = k + (size_t)j * C + 4 * c;
         for (int hb = blockIdx.y * LPG; hb < h; hb += gridDim.y * LPG) {  // head groups over blockIdx.y on small clouds
             float keep = 0.f;
+            float4 kv[LPG];
+#pragma unroll
+            for (int t = 0; t < LPG; t++) kv[t] = ldg4(krow + min(hb + t, h - 1) * D);  // all key rows of the group at once
 #pragma unroll
             for (int t = 0; t < LPG; t++) {
-                const int hh = hb + t;
-                if (hh < h) {
-                    float part = dot4(qs[hh * LPG + c], ldg4(krow + hh * D));
-                    float tot = xor_sum<1, LPG>(part);
-                    if (c == t) keep = tot;
-                }
+                float part = dot4(qs[min(hb + t, h - 1) * LPG + c], kv[t]);
+                float tot = xor_sum<1, LPG>(part);
+                if (c == t) keep = tot;
             }
             const int hh = hb + c;
             if (valid && hh < h) attn[(size_t)m * h + hh] = keep;
@@ -94,11 +94,18 @@ __global__ __launch_bounds__(256) void gather_accum_kernel(int N, int h, const i
                 const int wm = widx ? widx[slot] : slot;
                 const float *srow = src + (size_t)j * C + 4 * c;
                 const float *wrow = w + (size_t)wm * h;
+                // no per-head guards: a slot past the last head repeats it (its sum is not stored), so the HC weight and
+                // row loads of a pass are issued together instead of one dependent round trip per head
+                float wv[HC];
+                float4 sv[HC];
 #pragma unroll
                 for (int t = 0; t < HC; t++) {
-                    const int hh = hb + t;
-                    if (hh < h) acc[t] = fma4(wrow[hh], ldg4(srow + hh * D), acc[t]);
+                    const int hh = min(hb + t, h - 1);
+                    wv[t] = wrow[hh];
+                    sv[t] = ldg4(srow + hh * D);
                 }
+#pragma unroll
+                for (int t = 0; t < HC; t++) acc[t] = fma4(wv[t], sv[t], acc[t]);
             }
         }
 #pragma unroll

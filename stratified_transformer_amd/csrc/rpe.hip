@@ -40,11 +40,14 @@ __global__ __launch_bounds__(768, 6) void a2_fwd_kernel(int N, int h, int L, con
     stage_table<D>(Tk, table_k, L, h, h0, hgn);
     __syncthreads();
     const int wpb = blockDim.x >> 6;
+    // No per-head guards inside the walk: a head slot beyond the group's last head (only possible in the last head
+    // group when h is not a multiple of HG) repeats that last head and its result is never stored.  With a branch
+    // per head the compiler ends each head's block with a wait for its own key-row load, i.e. HG dependent memory
+    // round trips per pass instead of one.
     for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
         float4 q4[HG];
 #pragma unroll
-        for (int t = 0; t < HG; t++)
-            q4[t] = t < hgn ? ldg4(q + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
+        for (int t = 0; t < HG; t++) q4[t] = ldg4(q + (size_t)qi * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
         const int s = offs[qi], e = offs[qi + 1];
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int m = m0 + p;
@@ -52,15 +55,16 @@ __global__ __launch_bounds__(768, 6) void a2_fwd_kernel(int N, int h, int L, con
             const int mm = valid ? m : s;
             const int j = idx_k[mm];
             const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+            float4 k4[HG];
+#pragma unroll
+            for (int t = 0; t < HG; t++) k4[t] = ldg4(k + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
             float keep = 0.f;
 #pragma unroll
             for (int t = 0; t < HG; t++) {
-                if (t < hgn) {
-                    const float4 k4 = ldg4(k + (size_t)j * C + (h0 + t) * D + 4 * c);
-                    float part = dot4(q4[t], tsum<D>(Tq, L, t, r0, r1, r2, c)) + dot4(k4, tsum<D>(Tk, L, t, r0, r1, r2, c));
-                    float tot = xor_sum<1, LPG>(part);
-                    if (c == t) keep = tot;
-                }
+                const int te = min(t, hgn - 1);
+                float part = dot4(q4[t], tsum<D>(Tq, L, te, r0, r1, r2, c)) + dot4(k4[t], tsum<D>(Tk, L, te, r0, r1, r2, c));
+                float tot = xor_sum<1, LPG>(part);
+                if (c == t) keep = tot;
             }
             if (valid && c < hgn) out[(size_t)m * h + h0 + c] = keep;
         }
@@ -323,14 +327,17 @@ __global__ __launch_bounds__(512, 8) void a4_fwd_kernel(int N, int h, int L, con
             if (m < e) {
                 const int j = idx1[m];
                 const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
+                // no per-head guards (a2_fwd_kernel): a slot past the group's last head repeats it, its sum is not stored
+                float a[HG];
+                float4 v4[HG];
 #pragma unroll
                 for (int t = 0; t < HG; t++) {
-                    if (t < hgn) {
-                        const float a = attn[(size_t)m * h + h0 + t];
-                        const float4 v4 = ldg4(v + (size_t)j * C + (h0 + t) * D + 4 * c);
-                        acc[t] = fma4(a, add4(tsum<D>(Tv, L, t, r0, r1, r2, c), v4), acc[t]);
-                    }
+                    const int te = min(t, hgn - 1);
+                    a[t] = attn[(size_t)m * h + h0 + te];
+                    v4[t] = ldg4(v + (size_t)j * C + (h0 + te) * D + 4 * c);
                 }
+#pragma unroll
+                for (int t = 0; t < HG; t++) acc[t] = fma4(a[t], add4(tsum<D>(Tv, L, min(t, hgn - 1), r0, r1, r2, c), v4[t]), acc[t]);
             }
         }
 #pragma unroll
@@ -417,9 +424,18 @@ __global__ __launch_bounds__(256) void key_accum_kernel(int N, int h, const int 
             if (slot < e) {
                 const float *srow = src + (size_t)sidx[slot] * C + 4 * c;
                 const float *wrow = w + (size_t)widx[slot] * h;
+                // no per-head guards: a slot past the last head repeats it (its sum is not stored), so the HC weight and
+                // row loads of a pass are issued together instead of one dependent round trip per head
+                float wv[HC];
+                float4 sv[HC];
 #pragma unroll
-                for (int t = 0; t < HC; t++)
-                    if (hb + t < h) acc[t] = fma4(wrow[hb + t], ldg4(srow + (hb + t) * D), acc[t]);
+                for (int t = 0; t < HC; t++) {
+                    const int hh = min(hb + t, h - 1);
+                    wv[t] = wrow[hh];
+                    sv[t] = ldg4(srow + hh * D);
+                }
+#pragma unroll
+                for (int t = 0; t < HC; t++) acc[t] = fma4(wv[t], sv[t], acc[t]);
             }
         }
 #pragma unroll

@@ -69,13 +69,12 @@ __global__ __launch_bounds__(512, 8) void rows_table_sum_kernel(int N, int h, in
             if (slot < e) {
                 const int m = pair_map ? pair_map[slot] : slot;
                 const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
+                // no per-head guards (rpe.hip, a2_fwd_kernel): a slot past the group's last head repeats it
+                float g[HG];
 #pragma unroll
-                for (int t = 0; t < HG; t++) {
-                    if (t < hgn) {
-                        const float g = w[(size_t)m * h + h0 + t];
-                        acc[t] = fma4(g, tsum<D>(T, L, t, r0, r1, r2, c), acc[t]);
-                    }
-                }
+                for (int t = 0; t < HG; t++) g[t] = w[(size_t)m * h + h0 + min(t, hgn - 1)];
+#pragma unroll
+                for (int t = 0; t < HG; t++) acc[t] = fma4(g[t], tsum<D>(T, L, min(t, hgn - 1), r0, r1, r2, c), acc[t]);
             }
         }
 #pragma unroll
@@ -119,14 +118,14 @@ __global__ __launch_bounds__(512, 8) void a4_bwd_attn_kernel(int N, int h, int L
             const int j = idx1[mm];
             const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
             float keep = 0.f;
+            float4 v4[HG];
+#pragma unroll
+            for (int t = 0; t < HG; t++) v4[t] = ldg4(v + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
 #pragma unroll
             for (int t = 0; t < HG; t++) {
-                if (t < hgn) {
-                    const float4 v4 = ldg4(v + (size_t)j * C + (h0 + t) * D + 4 * c);
-                    float part = dot4(add4(tsum<D>(T, L, t, r0, r1, r2, c), v4), g4[t]);
-                    float tot = xor_sum<1, LPG>(part);
-                    if (c == t) keep = tot;
-                }
+                float part = dot4(add4(tsum<D>(T, L, min(t, hgn - 1), r0, r1, r2, c), v4[t]), g4[t]);
+                float tot = xor_sum<1, LPG>(part);
+                if (c == t) keep = tot;
             }
             if (valid && c < hgn) grad_attn[(size_t)m * h + h0 + c] = keep;
         }

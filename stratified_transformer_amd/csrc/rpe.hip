@@ -109,7 +109,7 @@ __global__ __launch_bounds__(768, 6) void wlogit_softmax_kernel(int N, int h, in
         float4 q4[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++)
-            q4[t] = t < hgn ? ldg4(q + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
+            q4[t] = ldg4(q + (size_t)qi * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
         const int s = offs[qi], e = offs[qi + 1];
         if (e <= s) continue;
         const int np = (e - s + PPW - 1) / PPW;
@@ -119,14 +119,15 @@ __global__ __launch_bounds__(768, 6) void wlogit_softmax_kernel(int N, int h, in
             const int j = idx_k[mm];
             const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
             float keep = 0.f;
+            float4 k4[HG];
+#pragma unroll
+            for (int t = 0; t < HG; t++) k4[t] = ldg4(k + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);  // no per-head guards
 #pragma unroll
             for (int t = 0; t < HG; t++) {
-                if (t < hgn) {
-                    const float4 k4 = ldg4(k + (size_t)j * C + (h0 + t) * D + 4 * c);
-                    const float a1 = xor_sum<1, LPG>(dot4(q4[t], k4));
-                    const float a2 = xor_sum<1, LPG>(dot4(q4[t], tsum<D>(Tq, L, t, r0, r1, r2, c)) + dot4(k4, tsum<D>(Tk, L, t, r0, r1, r2, c)));
-                    if (c == t) keep = a1 + a2;
-                }
+                const int te = min(t, hgn - 1);
+                const float a1 = xor_sum<1, LPG>(dot4(q4[t], k4[t]));
+                const float a2 = xor_sum<1, LPG>(dot4(q4[t], tsum<D>(Tq, L, te, r0, r1, r2, c)) + dot4(k4[t], tsum<D>(Tk, L, te, r0, r1, r2, c)));
+                if (c == t) keep = a1 + a2;
             }
             return keep;
         };

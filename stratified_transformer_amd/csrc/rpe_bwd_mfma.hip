@@ -371,13 +371,13 @@ __global__ __launch_bounds__(512, 4) void wattn_bwd_query_kernel(int N, int h, i
             const int j = idx1[mm];
             const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
             float keep = 0.f;
+            float4 v4[HG];
+#pragma unroll
+            for (int t = 0; t < HG; t++) v4[t] = ldg4(v + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);  // no per-head guards
 #pragma unroll
             for (int t = 0; t < HG; t++) {
-                if (t < hgn) {
-                    const float4 v4 = ldg4(v + (size_t)j * C + (h0 + t) * D + 4 * c);
-                    const float tot = xor_sum<1, LPG>(dot4(add4(tsum<D>(Tv, L, t, r0, r1, r2, c), v4), g4[t]));
-                    if (c == t) keep = tot;
-                }
+                const float tot = xor_sum<1, LPG>(dot4(add4(tsum<D>(Tv, L, min(t, hgn - 1), r0, r1, r2, c), v4[t]), g4[t]));
+                if (c == t) keep = tot;
             }
             return keep;
         };
@@ -386,13 +386,14 @@ __global__ __launch_bounds__(512, 4) void wattn_bwd_query_kernel(int N, int h, i
             const int mm = valid ? m : s;
             const int j = idx1[mm];
             const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+            float4 k4[HG];
+#pragma unroll
+            for (int t = 0; t < HG; t++) k4[t] = ldg4(k + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
 #pragma unroll
             for (int t = 0; t < HG; t++) {
-                const float w = quad_bcast(dl, t);
-                if (t < hgn && valid) {
-                    acc1[t] = fma4(w, ldg4(k + (size_t)j * C + (h0 + t) * D + 4 * c), acc1[t]);
-                    acc2[t] = fma4(w, tsum<D>(Tq, L, t, r0, r1, r2, c), acc2[t]);
-                }
+                const float w = valid ? quad_bcast(dl, t) : 0.f;  // a lane past the row's end adds zero
+                acc1[t] = fma4(w, k4[t], acc1[t]);
+                acc2[t] = fma4(w, tsum<D>(Tq, L, min(t, hgn - 1), r0, r1, r2, c), acc2[t]);
             }
         };
         if (e > s && np <= WB_MAXP) {
@@ -475,14 +476,21 @@ __global__ __launch_bounds__(512, 4) void wattn_bwd_key_kernel(int NK, int h, in
             if (slot < e) {
                 const int m = csc_pair[slot], i = csc_query[slot];
                 const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
+                float dl[HG], at[HG];
+                float4 q4[HG], g4[HG];
+#pragma unroll
+                for (int t = 0; t < HG; t++) {  // no per-head guards: all loads of the pass together
+                    const int te = min(t, hgn - 1);
+                    dl[t] = grad_logit[(size_t)m * h + h0 + te];
+                    at[t] = attn[(size_t)m * h + h0 + te];
+                    q4[t] = ldg4(q + (size_t)i * C + (h0 + te) * D + 4 * c);
+                    g4[t] = ldg4(go + (size_t)i * C + (h0 + te) * D + 4 * c);
+                }
 #pragma unroll
                 for (int t = 0; t < HG; t++) {
-                    if (t < hgn) {
-                        const float dl = grad_logit[(size_t)m * h + h0 + t], at = attn[(size_t)m * h + h0 + t];
-                        a1[t] = fma4(dl, ldg4(q + (size_t)i * C + (h0 + t) * D + 4 * c), a1[t]);
-                        a2[t] = fma4(dl, tsum<D>(Tk, L, t, r0, r1, r2, c), a2[t]);
-                        av[t] = fma4(at, ldg4(go + (size_t)i * C + (h0 + t) * D + 4 * c), av[t]);
-                    }
+                    a1[t] = fma4(dl[t], q4[t], a1[t]);
+                    a2[t] = fma4(dl[t], tsum<D>(Tk, L, min(t, hgn - 1), r0, r1, r2, c), a2[t]);
+                    av[t] = fma4(at[t], g4[t], av[t]);
                 }
             }
         }

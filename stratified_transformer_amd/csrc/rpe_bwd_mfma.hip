@@ -236,29 +236,40 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
             // The loads of ALL passes are issued before anything depends on them - pair id, then rel index
             // (lane c < 3: axis c) and weight (lane c < hgn: head c) - and stay in registers: one dependent
             // chain per segment instead of one per pass, and the sweep for the fixed-point scale re-reads nothing.
+            // Every load is UNCONDITIONAL, with a clamped index (a slot past the segment's end repeats its last pair, an
+            // idle lane reads its neighbour's value), and nothing consumes a loaded value before the last load is issued:
+            // a predicated load sits in a block of its own that ends with a wait for it, and the running max below,
+            // when it was folded into the load loop, made the weights eight dependent round trips.
             int mreg[TG_MAXP], rreg[TG_MAXP];
             float wreg[TG_MAXP];
 #pragma unroll
-            for (int i = 0; i < TG_MAXP; i++) {
-                const int slot = s + i * 16 + p;
-                mreg[i] = slot < e ? (pair_map ? pair_map[slot] : slot) : -1;
+            for (int i = 0; i < TG_MAXP; i++) { mreg[i] = -1; rreg[i] = 0; wreg[i] = 0.f; }
+            // the row of X: every lane loads (lanes >= 4*HG repeat head 0's quarters), only lanes < 4*HG store it below
+            const float4 x4 = ldg4(X + (size_t)row * C + (h0 + min(lane >> 2, hgn - 1) % HG) * D + 4 * c);
+            if (e > s) {  // wave-uniform (an empty row has nothing to read, and s may be one past the last pair)
+#pragma unroll
+                for (int i = 0; i < TG_MAXP; i++) {
+                    const int slot = min(s + i * 16 + p, e - 1);
+                    mreg[i] = pair_map ? pair_map[slot] : slot;
+                }
+#pragma unroll
+                for (int i = 0; i < TG_MAXP; i++) {
+                    rreg[i] = rel[mreg[i] * 3 + min(c, 2)];
+                    wreg[i] = w[(size_t)mreg[i] * h + h0 + min(c, hgn - 1)];
+                }
             }
             unsigned mxb = 0u;
 #pragma unroll
             for (int i = 0; i < TG_MAXP; i++) {
-                const int m = mreg[i];
-                rreg[i] = (m >= 0 && c < 3) ? rel[m * 3 + c] : 0;
-                wreg[i] = (m >= 0 && c < hgn) ? w[(size_t)m * h + h0 + c] : 0.f;
+                const bool live = s + i * 16 + p < e;
+                if (!live) mreg[i] = -1;
+                wreg[i] = (live && c < hgn) ? wreg[i] : 0.f;
                 mxb = max(mxb, __float_as_uint(fabsf(wreg[i])));
             }
             const FixScale sc = row_scale(wave_max_u32(mxb), e - s);
-            if (lane < HG * 4) {  // lane = t*4 + quarter: the X row, scaled by 2^-S
-                const int t = lane >> 2;
-                float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < hgn) x4 = ldg4(X + (size_t)row * C + (h0 + t) * D + 4 * c);
-                *reinterpret_cast<float4 *>(&xs[(wave * HG + t) * 16 + 4 * c]) =
+            if (lane < HG * 4)  // lane = t*4 + quarter: the X row (loaded with the batch above), scaled by 2^-S
+                *reinterpret_cast<float4 *>(&xs[(wave * HG + (lane >> 2)) * 16 + 4 * c]) =
                     make_float4(x4.x * sc.inv, x4.y * sc.inv, x4.z * sc.inv, x4.w * sc.inv);
-            }
 #pragma unroll
             for (int i = 0; i < TG_MAXP; i++) {
                 if (i < np) {  // wave-uniform

@@ -87,6 +87,11 @@ __global__ __launch_bounds__(256) void gather_accum_kernel(int N, int h, const i
         float4 acc[HC];
 #pragma unroll
         for (int t = 0; t < HC; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 prev[HC];  // ACCUMULATE: the row's running sum, requested now and consumed after the walk
+        if (ACCUMULATE) {
+#pragma unroll
+            for (int t = 0; t < HC; t++) prev[t] = ldg4(out + (size_t)row * C + min(hb + t, h - 1) * D + 4 * c);
+        }
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int slot = m0 + p;
             if (slot < e) {
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void gather_accum_kernel(int N, int h, const i
                 float4 tot = xor_sum4<LPG, 64>(acc[t]);
                 if (p == 0) {
                     float *o = out + (size_t)row * C + hh * D + 4 * c;
-                    if (ACCUMULATE) tot = add4(tot, ldg4(o));
+                    if (ACCUMULATE) tot = add4(tot, prev[t]);
                     stg4(o, tot);
                 }
             }

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void a2_bwd_key_kernel(int N, int h, int L, co
 // A4 forward: out[q,hh,:] = sum_m attn[m,hh] * (v[idx1[m],hh,:] + Tv(m,hh,:))
 // ------------------------------------------------------------------------------------------------
 template <int D, int HG>
-__global__ __launch_bounds__(512, 8) void a4_fwd_kernel(int N, int h, int L, const float *__restrict__ attn,
+__global__ __launch_bounds__(512, 6) void a4_fwd_kernel(int N, int h, int L, const float *__restrict__ attn,
                                                         const float *__restrict__ v, const int *__restrict__ offs,
                                                         const int *__restrict__ idx1, const float *__restrict__ table,
                                                         const int *__restrict__ rel, float *__restrict__ out) {
@@ -326,17 +326,18 @@ __global__ __launch_bounds__(512, 8) void a4_fwd_kernel(int N, int h, int L, con
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int m = m0 + p;
             if (m < e) {
-                const int j = idx1[m];
-                const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
-                // no per-head guards (a2_fwd_kernel): a slot past the group's last head repeats it, its sum is not stored
+                // no per-head guards (a2_fwd_kernel): a slot past the group's last head repeats it, its sum is not stored.
+                // The weights depend on m alone, so they travel with the pair's ids; the value rows follow in one batch.
                 float a[HG];
+#pragma unroll
+                for (int t = 0; t < HG; t++) a[t] = attn[(size_t)m * h + h0 + min(t, hgn - 1)];
+                const int j = idx1[m];
+                const int q0 = rel[m * 3 + 0], q1 = rel[m * 3 + 1], q2 = rel[m * 3 + 2];
+                __builtin_amdgcn_sched_barrier(0);
+                const int r0 = clampr(q0, L), r1 = clampr(q1, L), r2 = clampr(q2, L);
                 float4 v4[HG];
 #pragma unroll
-                for (int t = 0; t < HG; t++) {
-                    const int te = min(t, hgn - 1);
-                    a[t] = attn[(size_t)m * h + h0 + te];
-                    v4[t] = ldg4(v + (size_t)j * C + (h0 + te) * D + 4 * c);
-                }
+                for (int t = 0; t < HG; t++) v4[t] = ldg4(v + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
 #pragma unroll
                 for (int t = 0; t < HG; t++) acc[t] = fma4(a[t], add4(tsum<D>(Tv, L, min(t, hgn - 1), r0, r1, r2, c), v4[t]), acc[t]);
             }
@@ -687,12 +688,12 @@ void attention_step2_with_rel_pos_value_forward_cuda_launcher_v2(int N, int M, i
     hipStream_t st = state().stream;
     if (hdim == 16) P2_LAUNCH_HG(16, 1, {
         allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
-        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 8, 4), ngroups), dim3(512), lds_bytes, st,
+        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 8, 3), ngroups), dim3(512), lds_bytes, st,
                            N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output);
     })
     else if (hdim == 32) P2_LAUNCH_HG(32, 1, {
         allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
-        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 8, 4), ngroups), dim3(512), lds_bytes, st,
+        hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 8, 3), ngroups), dim3(512), lds_bytes, st,
                            N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output);
     })
     else { set_error("d != 16 and d != 32"); return; }

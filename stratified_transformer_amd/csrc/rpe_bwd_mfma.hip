@@ -64,15 +64,23 @@ __global__ __launch_bounds__(512, 8) void rows_table_sum_kernel(int N, int h, in
 #pragma unroll
         for (int t = 0; t < HG; t++) acc[t] = make_float4(0, 0, 0, 0);
         const int s = offs[row], e = offs[row + 1];
+        float4 prev[HG];  // ACCUM_OUT: the row's running sum, requested now and consumed after the walk
+        if (ACCUM_OUT) {
+#pragma unroll
+            for (int t = 0; t < HG; t++) prev[t] = ldg4(grad_x + (size_t)row * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
+        }
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int slot = m0 + p;
             if (slot < e) {
                 const int m = pair_map ? pair_map[slot] : slot;
-                const int r0 = clampr(rel[m * 3 + 0], L), r1 = clampr(rel[m * 3 + 1], L), r2 = clampr(rel[m * 3 + 2], L);
-                // no per-head guards (rpe.hip, a2_fwd_kernel): a slot past the group's last head repeats it
+                // no per-head guards (rpe.hip, a2_fwd_kernel): a slot past the group's last head repeats it.  The
+                // scheduling fence keeps the clamps (the first use of rel) behind the weight loads: one round trip.
+                const int q0 = rel[m * 3 + 0], q1 = rel[m * 3 + 1], q2 = rel[m * 3 + 2];
                 float g[HG];
 #pragma unroll
                 for (int t = 0; t < HG; t++) g[t] = w[(size_t)m * h + h0 + min(t, hgn - 1)];
+                __builtin_amdgcn_sched_barrier(0);
+                const int r0 = clampr(q0, L), r1 = clampr(q1, L), r2 = clampr(q2, L);
 #pragma unroll
                 for (int t = 0; t < HG; t++) acc[t] = fma4(g[t], tsum<D>(T, L, min(t, hgn - 1), r0, r1, r2, c), acc[t]);
             }
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(512, 8) void rows_table_sum_kernel(int N, int h, in
                 float4 tot = xor_sum4<LPG, 64>(acc[t]);
                 if (p == 0) {
                     float *o = grad_x + (size_t)row * C + (h0 + t) * D + 4 * c;
-                    if (ACCUM_OUT) tot = add4(tot, ldg4(o));
+                    if (ACCUM_OUT) tot = add4(tot, prev[t]);
                     stg4(o, tot);
                 }
             }

@@ -39,10 +39,12 @@ __global__ __launch_bounds__(256) void a1_fwd_kernel(int N, int h, const float *
     __builtin_amdgcn_wave_barrier();
     const int p = lane / LPG, c = lane % LPG;
     const int s = offs[qi], e = offs[qi + 1];
+    int jn = idx1[max(0, min(s + p, e - 1))];  // the key id of the next pass travels with the key rows of this one
     for (int m0 = s; m0 < e; m0 += PPW) {
         const int m = m0 + p;
         const bool valid = m < e;
-        const int j = idx1[valid ? m : s];
+        const int j = jn;
+        jn = idx1[min(m + PPW, e - 1)];
         const float *krow = k + (size_t)j * C + 4 * c;
         for (int hb = blockIdx.y * LPG; hb < h; hb += gridDim.y * LPG) {  // head groups over blockIdx.y on small clouds
             float keep = 0.f;
@@ -92,15 +94,20 @@ __global__ __launch_bounds__(256) void gather_accum_kernel(int N, int h, const i
 #pragma unroll
             for (int t = 0; t < HC; t++) prev[t] = ldg4(out + (size_t)row * C + min(hb + t, h - 1) * D + 4 * c);
         }
+        // the ids of the next pass are requested together with the weights and rows of this one (one round trip per
+        // pass); a slot past the row's end repeats the row's last slot and is not added
+        const int first = max(0, min(s + p, e - 1));
+        int sn = sidx[first], wn = ACCUMULATE ? widx[first] : first;  // by key: CSC pair ids; by query: identity
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int slot = m0 + p;
+            const int nslot = min(slot + PPW, e - 1);
+            const float *srow = src + (size_t)sn * C + 4 * c;
+            const float *wrow = w + (size_t)wn * h;
+            sn = sidx[nslot];
+            wn = ACCUMULATE ? widx[nslot] : nslot;
+            // no per-head guards: a slot past the last head repeats it (its sum is not stored), so the HC weight and
+            // row loads of a pass are issued together instead of one dependent round trip per head
             if (slot < e) {
-                const int j = sidx[slot];
-                const int wm = widx ? widx[slot] : slot;
-                const float *srow = src + (size_t)j * C + 4 * c;
-                const float *wrow = w + (size_t)wm * h;
-                // no per-head guards: a slot past the last head repeats it (its sum is not stored), so the HC weight and
-                // row loads of a pass are issued together instead of one dependent round trip per head
                 float wv[HC];
                 float4 sv[HC];
 #pragma unroll
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(256) void gather_accum_kernel(int N, int h, const i
                     wv[t] = wrow[hh];
                     sv[t] = ldg4(srow + hh * D);
                 }
+                __builtin_amdgcn_sched_barrier(0);  // every load of the pass before its first use
 #pragma unroll
                 for (int t = 0; t < HC; t++) acc[t] = fma4(wv[t], sv[t], acc[t]);
             }

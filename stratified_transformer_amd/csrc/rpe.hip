@@ -49,15 +49,18 @@ __global__ __launch_bounds__(768, 6) void a2_fwd_kernel(int N, int h, int L, con
 #pragma unroll
         for (int t = 0; t < HG; t++) q4[t] = ldg4(q + (size_t)qi * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
         const int s = offs[qi], e = offs[qi + 1];
+        // the ids of the next pass are requested together with the key rows of this one: one round trip per pass
+        PairIds nx = load_pair_ids(idx_k, rel, max(0, min(s + p, e - 1)));
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int m = m0 + p;
             const bool valid = m < e;
-            const int mm = valid ? m : s;
-            const int j = idx_k[mm];
-            const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+            const PairIds cur = nx;
+            nx = load_pair_ids(idx_k, rel, min(m + PPW, e - 1));
             float4 k4[HG];
 #pragma unroll
-            for (int t = 0; t < HG; t++) k4[t] = ldg4(k + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
+            for (int t = 0; t < HG; t++) k4[t] = ldg4(k + (size_t)cur.j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
+            __builtin_amdgcn_sched_barrier(0);
+            const int r0 = clampr(cur.q0, L), r1 = clampr(cur.q1, L), r2 = clampr(cur.q2, L);
             float keep = 0.f;
 #pragma unroll
             for (int t = 0; t < HG; t++) {
@@ -323,21 +326,25 @@ __global__ __launch_bounds__(512, 6) void a4_fwd_kernel(int N, int h, int L, con
 #pragma unroll
         for (int t = 0; t < HG; t++) acc[t] = make_float4(0, 0, 0, 0);
         const int s = offs[qi], e = offs[qi + 1];
+        // no per-head guards (a2_fwd_kernel): a slot past the group's last head repeats it, its sum is not stored.
+        // The ids of the next pass are requested together with the weights and value rows of this one (one round
+        // trip per pass); a slot past the row's end repeats the row's last pair with weight zero.
+        PairIds nx = load_pair_ids(idx1, rel, max(0, min(s + p, e - 1)));
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int m = m0 + p;
+            const int mm = min(m, e - 1);
+            const PairIds cur = nx;
+            nx = load_pair_ids(idx1, rel, min(m + PPW, e - 1));
+            float a[HG];
+            float4 v4[HG];
+#pragma unroll
+            for (int t = 0; t < HG; t++) {
+                a[t] = attn[(size_t)mm * h + h0 + min(t, hgn - 1)];
+                v4[t] = ldg4(v + (size_t)cur.j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int r0 = clampr(cur.q0, L), r1 = clampr(cur.q1, L), r2 = clampr(cur.q2, L);
             if (m < e) {
-                // no per-head guards (a2_fwd_kernel): a slot past the group's last head repeats it, its sum is not stored.
-                // The weights depend on m alone, so they travel with the pair's ids; the value rows follow in one batch.
-                float a[HG];
-#pragma unroll
-                for (int t = 0; t < HG; t++) a[t] = attn[(size_t)m * h + h0 + min(t, hgn - 1)];
-                const int j = idx1[m];
-                const int q0 = rel[m * 3 + 0], q1 = rel[m * 3 + 1], q2 = rel[m * 3 + 2];
-                __builtin_amdgcn_sched_barrier(0);
-                const int r0 = clampr(q0, L), r1 = clampr(q1, L), r2 = clampr(q2, L);
-                float4 v4[HG];
-#pragma unroll
-                for (int t = 0; t < HG; t++) v4[t] = ldg4(v + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
 #pragma unroll
                 for (int t = 0; t < HG; t++) acc[t] = fma4(a[t], add4(tsum<D>(Tv, L, min(t, hgn - 1), r0, r1, r2, c), v4[t]), acc[t]);
             }
@@ -421,13 +428,23 @@ __global__ __launch_bounds__(256) void key_accum_kernel(int N, int h, const int 
         float4 acc[HC];
 #pragma unroll
         for (int t = 0; t < HC; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 prev[HC];  // the row's running sum, requested now and consumed after the walk
+#pragma unroll
+        for (int t = 0; t < HC; t++) prev[t] = ldg4(out + (size_t)row * C + min(hb + t, h - 1) * D + 4 * c);
+        // the ids of the next pass are requested together with the weights and rows of this one (one round trip per
+        // pass); a slot past the row's end repeats the row's last slot and is not added
+        const int first = max(0, min(s + p, e - 1));
+        int sn = sidx[first], wn = widx[first];
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int slot = m0 + p;
+            const int nslot = min(slot + PPW, e - 1);
+            const float *srow = src + (size_t)sn * C + 4 * c;
+            const float *wrow = w + (size_t)wn * h;
+            sn = sidx[nslot];
+            wn = widx[nslot];
+            // no per-head guards: a slot past the last head repeats it (its sum is not stored), so the HC weight and
+            // row loads of a pass are issued together instead of one dependent round trip per head
             if (slot < e) {
-                const float *srow = src + (size_t)sidx[slot] * C + 4 * c;
-                const float *wrow = w + (size_t)widx[slot] * h;
-                // no per-head guards: a slot past the last head repeats it (its sum is not stored), so the HC weight and
-                // row loads of a pass are issued together instead of one dependent round trip per head
                 float wv[HC];
                 float4 sv[HC];
 #pragma unroll
@@ -436,6 +453,7 @@ __global__ __launch_bounds__(256) void key_accum_kernel(int N, int h, const int 
                     wv[t] = wrow[hh];
                     sv[t] = ldg4(srow + hh * D);
                 }
+                __builtin_amdgcn_sched_barrier(0);  // every load of the pass before its first use
 #pragma unroll
                 for (int t = 0; t < HC; t++) acc[t] = fma4(wv[t], sv[t], acc[t]);
             }
@@ -444,10 +462,7 @@ __global__ __launch_bounds__(256) void key_accum_kernel(int N, int h, const int 
         for (int t = 0; t < HC; t++) {
             if (hb + t < h) {
                 float4 tot = xor_sum4<LPG, 64>(acc[t]);
-                if (p == 0) {
-                    float *o = out + (size_t)row * C + (hb + t) * D + 4 * c;
-                    stg4(o, add4(tot, ldg4(o)));
-                }
+                if (p == 0) stg4(out + (size_t)row * C + (hb + t) * D + 4 * c, add4(tot, prev[t]));
             }
         }
     }

@@ -69,10 +69,13 @@ __global__ __launch_bounds__(512, 8) void rows_table_sum_kernel(int N, int h, in
 #pragma unroll
             for (int t = 0; t < HG; t++) prev[t] = ldg4(grad_x + (size_t)row * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
         }
+        // by key (ACCUM_OUT) the pair id of the next pass is requested together with the weights of this one
+        int mn = ACCUM_OUT ? pair_map[max(0, min(s + p, e - 1))] : 0;
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int slot = m0 + p;
+            const int m = ACCUM_OUT ? mn : slot;
+            if (ACCUM_OUT) mn = pair_map[min(slot + PPW, e - 1)];
             if (slot < e) {
-                const int m = pair_map ? pair_map[slot] : slot;
                 // no per-head guards (rpe.hip, a2_fwd_kernel): a slot past the group's last head repeats it.  The
                 // scheduling fence keeps the clamps (the first use of rel) behind the weight loads: one round trip.
                 const int q0 = rel[m * 3 + 0], q1 = rel[m * 3 + 1], q2 = rel[m * 3 + 2];
@@ -119,16 +122,20 @@ __global__ __launch_bounds__(512, 8) void a4_bwd_attn_kernel(int N, int h, int L
         for (int t = 0; t < HG; t++)
             g4[t] = t < hgn ? ldg4(go + (size_t)qi * C + (h0 + t) * D + 4 * c) : make_float4(0, 0, 0, 0);
         const int s = offs[qi], e = offs[qi + 1];
+        // the ids of the next pass are requested together with the value rows of this one: one round trip per pass
+        PairIds nx = load_pair_ids(idx1, rel, max(0, min(s + p, e - 1)));
         for (int m0 = s; m0 < e; m0 += PPW) {
             const int m = m0 + p;
             const bool valid = m < e;
-            const int mm = valid ? m : s;
-            const int j = idx1[mm];
-            const int r0 = clampr(rel[mm * 3 + 0], L), r1 = clampr(rel[mm * 3 + 1], L), r2 = clampr(rel[mm * 3 + 2], L);
+            const PairIds cur = nx;
+            nx = load_pair_ids(idx1, rel, min(m + PPW, e - 1));
+            const int j = cur.j;
             float keep = 0.f;
             float4 v4[HG];
 #pragma unroll
             for (int t = 0; t < HG; t++) v4[t] = ldg4(v + (size_t)j * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
+            __builtin_amdgcn_sched_barrier(0);
+            const int r0 = clampr(cur.q0, L), r1 = clampr(cur.q1, L), r2 = clampr(cur.q2, L);
 #pragma unroll
             for (int t = 0; t < HG; t++) {
                 float part = dot4(add4(tsum<D>(T, L, min(t, hgn - 1), r0, r1, r2, c), v4[t]), g4[t]);
@@ -223,20 +230,29 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
     const int rb = min(N, (int)blockIdx.x * per), re = min(N, rb + per);
     if (threadIdx.x == 0) next_row = rb;
     __syncthreads();
+    // A wave claims its next row, and requests that row's bounds, while it still works on the last segment of the
+    // current one: the claim (an LDS round trip) and the bounds (a memory round trip) are off the dependent chain
+    // of the segment that uses them.
+    auto claim = [&]() -> int {
+        int r = 0;
+        if (lane == 0) r = atomicAdd(&next_row, 1);
+        r = __builtin_amdgcn_readfirstlane(r);
+        return r < re ? r : -1;
+    };
     int row = -1, cur = 0, end = 0;
+    int nrow = claim(), ncur = 0, nend = 0;
+    if (nrow >= 0) {
+        ncur = offs[nrow];
+        nend = offs[nrow + 1];
+    }
     for (;;) {
-        if (cur >= end) {  // this wave's row is finished: take the next one
-            int r = 0;
-            if (lane == 0) r = atomicAdd(&next_row, 1);
-            r = __builtin_amdgcn_readfirstlane(r);
-            if (r < re) {
-                row = r;
-                cur = offs[row];
-                end = offs[row + 1];
-            } else {
-                row = -1;
-            }
+        if (cur >= end) {  // this wave's row is finished: take the claimed one (none left: row = -1 from here on)
+            row = nrow;
+            cur = row >= 0 ? ncur : 0;
+            end = row >= 0 ? nend : 0;
+            nrow = -1;
         }
+        const bool last_segment = row >= 0 && end - cur <= 16 * TG_MAXP;
         if (row >= 0) {
             const int s = cur, e = min(end, cur + 16 * TG_MAXP);
             cur = e;
@@ -260,6 +276,15 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
                     const int slot = min(s + i * 16 + p, e - 1);
                     mreg[i] = pair_map ? pair_map[slot] : slot;
                 }
+            }
+            if (last_segment) {  // wave-uniform; behind the pair ids so that the claim's LDS round trip overlaps them
+                nrow = claim();
+                if (nrow >= 0) {
+                    ncur = offs[nrow];
+                    nend = offs[nrow + 1];
+                }
+            }
+            if (e > s) {
 #pragma unroll
                 for (int i = 0; i < TG_MAXP; i++) {
                     rreg[i] = rel[mreg[i] * 3 + min(c, 2)];

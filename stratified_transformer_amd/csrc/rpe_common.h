@@ -70,6 +70,18 @@ __device__ __forceinline__ int clampr(int r, int L) { return min(max(r, 0), L - 
     const int tsz = hgn * 3 * L * D;                                                \
     (void)PPW; (void)p; (void)tsz; (void)C; (void)c; (void)wave;
 
+// a pair's key id and its three (unclamped) table rows, as one unit the walkers request a pass ahead
+struct PairIds {
+    int j, q0, q1, q2;
+};
+__device__ __forceinline__ PairIds load_pair_ids(const int *__restrict__ idx1, const int *__restrict__ rel, int m) {
+    PairIds r;
+    r.j = idx1[m];
+    r.q0 = rel[m * 3 + 0];
+    r.q1 = rel[m * 3 + 1];
+    r.q2 = rel[m * 3 + 2];
+    return r;
+}
 
 // rpe_bwd_mfma.hip
 bool a2_bwd_mfma(int N, int NK, int M, int h, int hdim, int L, const float *go, const float *q, const int *offs, const float *k,

@@ -25,6 +25,11 @@ import time
 import numpy as np
 import torch
 
+# Hardware queues of the HIP runtime (read when the runtime initialises, i.e. at the first device call below): with
+# the default of 4 the ~15 streams of the lanes share queues and a sampler kernel of one batch blocks unrelated
+# kernels of another that happen to sit behind it in the same queue.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -65,46 +70,73 @@ def run_gpu(args, rank, world):
     offset = torch.tensor([N_POINTS], dtype=torch.int32, device=dev)
 
     states, results = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + rank)  # creates resident tensors
-    for _ in range(max(args.warmup - 1, 0)):
-        pipeline.scene_pass(xyz, offset, cfg, states)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if world > 1:
+            t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t.item())
+        return seconds
+
+    # One lane = one set of streams + one set of resident state tensors.  With L lanes the sampling chains (FPS, kNN:
+    # functions of the coordinates alone, one workgroup wide for most of their time) of the next L-1 batches are
+    # queued in front of the index builds and attention blocks of batch k, the way a training loop prefetches its
+    # data-side geometry; the forward+backward of consecutive batches stay strictly in order (an event between
+    # them, where the optimizer step would sit).  Same kernels, same results as a pass on its own (checked below).
+    lanes = []
+    for li in range(args.in_flight):
+        lane_stream = torch.cuda.Stream(dev)
+        lane_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(lane_stream):
+            lane_states, _ = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + rank, lane=li)
+        lanes.append((lane_stream, lane_states))
+    barrier()
+    if args.warmup > 0:
+        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.warmup)
     # In the timed region only the sampler launches (the dominant op, 7 per pass) carry event pairs; the
-    # per-op table of all components comes from the same passes run again afterwards with events around every
+    # per-op table of all components comes from passes run again afterwards with events around every
     # op (~270 event records per pass are host work, and the late stages are close to host-bound).
     live = pipeline.Timer(True, only=("fps/",))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        states, results = pipeline.scene_pass(xyz, offset, cfg, states, live)
+    last = pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, timer=live)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    # one batch at a time (the latency of a pass on its own), on the default stream
+    pipeline.scene_pass(xyz, offset, cfg, states)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        states, results = pipeline.scene_pass(xyz, offset, cfg, states)
+    barrier()
+    single_elapsed = max_over_ranks(time.perf_counter() - t1)
+    same = True
+    for lane_results in last:
+        if lane_results is None:
+            continue
+        for a, b in zip(results, lane_results):
+            same = same and torch.equal(a["downsample_idx"], b["downsample_idx"]) and torch.equal(a["even"].index_1, b["even"].index_1) \
+                and torch.equal(a["odd"].rel_idx, b["odd"].rel_idx) and torch.equal(a["out"], b["out"])
     timer = pipeline.Timer(True)
     for _ in range(args.steps):
         states, results = pipeline.scene_pass(xyz, offset, cfg, states, timer)
     barrier()
     # the optional fused module on the same passes: reported beside the headline, which stays on
     # the reference's operator API
-    pipeline.scene_pass(xyz, offset, cfg, states, fused=True)
+    pipeline.passes_in_flight([xyz], [offset], cfg, lanes, min(args.warmup, 2) or 1, fused=True)
     barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        pipeline.scene_pass(xyz, offset, cfg, states, fused=True)
+    t2 = time.perf_counter()
+    pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=True)
     barrier()
-    fused_elapsed = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([fused_elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        fused_elapsed = float(t.item())
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return dict(cfg=cfg, xyz_np=xyz_np, states=states, results=results, timer=timer, live=live, elapsed=elapsed, fused_elapsed=fused_elapsed, dev=dev)
+    fused_elapsed = max_over_ranks(time.perf_counter() - t2)
+    return dict(cfg=cfg, xyz_np=xyz_np, states=states, results=results, timer=timer, live=live, elapsed=elapsed, fused_elapsed=fused_elapsed,
+                single_elapsed=single_elapsed, inflight_same=bool(same), dev=dev)
 
 
 def component_table(timer, steps):
@@ -238,6 +270,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight (lanes); 1 = one batch at a time")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -262,9 +295,14 @@ def main():
                                    "unit = index build + FPS + depth x (A1,A2,add,A3,A4 fwd+bwd) + TransitionDown FPS/kNN16 + Upsample kNN3 per stage",
                        "points_per_gpu": N_POINTS, "pairs_stage0": run["results"][0]["M_even"],
                        "stage_points": [r["n"] for r in run["results"]], "parallelism": "1 scene per rank, no data-path collective"},
-            "overlap": "sampling chain, kNN and the next stage's index build on side streams beside the attention blocks; components_ms_per_step are per-op device times (fps/*: events inside the timed region; the others: the same passes repeated with events around every op) and overlap in wall time",
+            "overlap": "within a batch: sampling chain, kNN and the next stage's index build on side streams beside the attention blocks; across batches: the sampling chains of the next batches_in_flight-1 batches are queued ahead (data-side prefetch), forward+backward of consecutive batches strictly in order; components_ms_per_step are per-op device times (fps/*: events inside the timed region; the others: single passes repeated with events around every op) and overlap in wall time",
+            "batches_in_flight": args.in_flight,
+            "same_results_as_single_pass": run["inflight_same"],
+            "single_batch": {"ms_per_step": round(run["single_elapsed"] / args.steps * 1e3, 3),
+                             "value": round(N_POINTS * world / (run["single_elapsed"] / args.steps), 1),
+                             "note": "the same K passes one batch at a time on the default stream (latency of a pass on its own) in this process, i.e. with GPU_MAX_HW_QUEUES=%s; with the runtime's default of 4 hardware queues a pass on its own takes ~38 ms (profiles/)" % os.environ.get("GPU_MAX_HW_QUEUES", "default")},
             "fused_module": {"ms_per_step": round(run["fused_elapsed"] / args.steps * 1e3, 3),
-                             "note": "same passes with stratified_transformer_amd.fused.window_attention (fused logits+softmax forward, two-walk backward, one autograd node) instead of the five operators; not the headline"},
+                             "note": "same timed loop with stratified_transformer_amd.fused.window_attention (fused logits+softmax forward, two-walk backward, one autograd node) instead of the five operators; not the headline"},
             "roofline": roofline(comp, run),
             "roofline_attention": roofline(comp, run, among="attn"),
             "components_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(comp.items())},

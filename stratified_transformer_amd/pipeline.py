@@ -146,30 +146,52 @@ def geometry_stream(device, which=0):
     which only consume the sampling chain's results and nobody on the chain waits for."""
     key = (torch.device(device).index, which)
     if key not in _GEO_STREAMS:
+        # (a high-priority queue for the sampling chain was measured and does not help: 38.0 -> 41.9 ms per pass)
         _GEO_STREAMS[key] = torch.cuda.Stream(device=device)
     return _GEO_STREAMS[key]
 
 
-def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False):
-    """Runs the whole unit once.  `states` (list of StageState) carries the resident synthetic tensors;
+def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0):
+    """Runs the whole unit once (both phases of scene_pass_phases back to back).  Returns (states, results)."""
+    gen = scene_pass_phases(xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane)
+    next(gen)
+    try:
+        next(gen)
+    except StopIteration as done:
+        return done.value
+    raise RuntimeError("scene_pass_phases yielded twice")
+
+
+def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0):
+    """Generator form of scene_pass: the first next() enqueues the geometry chain of ALL stages (no host sync in
+    it) and yields; the second runs the index builds (which stop the host: key width, pair count) and the attention
+    blocks, and returns (states, results) through StopIteration.  passes_in_flight puts the first phase of the next
+    batch in front of the second phase of this one.
+
+    Runs the whole unit once.  `states` (list of StageState) carries the resident synthetic tensors;
     pass None on the first call to have them created (not timed by bench.py).  Returns (states, results).
 
     overlap=True: the geometry chain of all stages (stratified FPS, its continuation to the TransitionDown
     sample count, the gather of the next stage's points, kNN-16, kNN-3) is enqueued on a side stream; the
     main stream (index build + attention forward/backward) only waits for the first n//scale+1 samples of
-    its own stage.  Nothing is skipped and every dependency is an event; results are identical."""
+    its own stage.  Nothing is skipped and every dependency is an event; results are identical.
+
+    lane: which set of side streams the pass uses.  Two passes over different batches that are enqueued under
+    different current streams, with different lanes and different `states`, share no stream and no tensor they
+    write, so the device may run them side by side (passes_in_flight): the sampling chain of the next batch - one
+    CU wide, and a function of the coordinates alone - then runs beside the attention blocks of this one."""
     timer = timer or Timer(False)
     # nothing is carried over from an earlier pass: the CSC transpositions and the FPS sampler state are
     # rebuilt inside every pass (they are reused only WITHIN a pass, between blocks / the two FPS calls of a stage)
     P.clear_caches()
     dev = xyz.device
     main = torch.cuda.current_stream(dev)
-    geo = geometry_stream(dev) if overlap else main
-    knn_s = geometry_stream(dev, 1) if overlap else main
+    geo = geometry_stream(dev, 3 * lane) if overlap else main
+    knn_s = geometry_stream(dev, 3 * lane + 1) if overlap else main
     if overlap:
         geo.wait_stream(main)
         knn_s.wait_stream(main)
-        geometry_stream(dev, 2).wait_stream(main)
+        geometry_stream(dev, 3 * lane + 2).wait_stream(main)
     offset_host = [int(o) for o in offset.tolist()]
     P.hint_host_offsets(offset, offset_host)
     make = states is None
@@ -216,7 +238,7 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
     # The loop is software-pipelined on the HOST: while the attention blocks of stage s run on the main stream,
     # the geometry of stage s+1 is already queued on the geometry stream and its index build - whose two host
     # syncs (key width, pair count) would otherwise stop the launches - is done on a third stream.
-    idx_s = geometry_stream(dev, 2) if overlap else main
+    idx_s = geometry_stream(dev, 3 * lane + 2) if overlap else main
     stages = list(range(first, len(cfg.stages)))
     clouds = {}   # si -> (xyz, off, off_host)
     geo_out = {}  # si -> (ds, ev_ds, knn_idx or None)
@@ -255,23 +277,23 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
             ev_idx.record(idx_s)
         idx_out[si] = (even, odd, ev_idx)
 
-    geometry(first)
+    for si in stages:
+        geometry(si)
+    # Upsample chain (:479-480): interpolate from the coarse stage back to each finer one (kNN k=up_k)
+    if overlap:
+        knn_s.wait_stream(geo)
+    with torch.cuda.stream(knn_s):
+        for fine in reversed(stages[:-1]):
+            cx, coff, _ = clouds[fine + 1]
+            fx, foff, _ = clouds[fine]
+            timer.run("knn/k3", P.knnquery, cfg.up_k, cx, fx, coff, foff)
+    after = yield "geometry queued"
+    if after is not None:  # passes_in_flight: the attention blocks of this batch follow those of the previous one
+        main.wait_event(after)
     index(first)
     for si in stages:
         st = cfg.stages[si]
         x, off, _ = clouds[si]
-        if si + 1 in stages:
-            geometry(si + 1)
-        if si == stages[-1]:
-            # Upsample chain (:479-480): interpolate from the coarse stage back to each finer one (kNN k=up_k);
-            # every cloud is queued by now
-            if overlap:
-                knn_s.wait_stream(geo)
-            with torch.cuda.stream(knn_s):
-                for fine in reversed(stages[:-1]):
-                    cx, coff, _ = clouds[fine + 1]
-                    fx, foff, _ = clouds[fine]
-                    timer.run("knn/k3", P.knnquery, cfg.up_k, cx, fx, coff, foff)
         even, odd, ev_idx = idx_out[si]
         ds, _, knn_idx = geo_out[si]
         if overlap:
@@ -304,3 +326,38 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
         main.wait_stream(knn_s)
         main.wait_stream(idx_s)
     return states, results
+
+
+def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused=False):
+    """`steps` passes, batch k on lane k % len(lanes); lanes = [(stream, states), ...], one set of resident state
+    tensors per lane.  The geometry chains of the next len(lanes)-1 batches are queued in front of the index builds
+    and attention blocks of batch k (scene_pass_phases); nothing is shared between two lanes but the read-only inputs.  The caller synchronizes the device before and after.
+    Returns the results of the last pass of every lane."""
+    last = [None] * len(lanes)
+
+    def start(k):
+        stream, states = lanes[k % len(lanes)]
+        with torch.cuda.stream(stream):
+            gen = scene_pass_phases(xyz_list[k % len(xyz_list)], offset_list[k % len(offset_list)], cfg, states, timer,
+                                    fused=fused, lane=k % len(lanes))
+            next(gen)  # the geometry chain of batch k is queued
+        return gen
+
+    prev_done = None
+    ahead = len(lanes) - 1  # geometry phases queued in front of the attention phase being enqueued
+    queue = [start(k) for k in range(min(ahead, steps))]
+    for k in range(steps):
+        if k + ahead < steps:
+            queue.append(start(k + ahead))
+        gen = queue.pop(0)
+        with torch.cuda.stream(lanes[k % len(lanes)][0]):
+            try:
+                gen.send(prev_done)
+                raise RuntimeError("scene_pass_phases yielded twice")
+            except StopIteration as done:
+                _, last[k % len(lanes)] = done.value
+            # the forward+backward of batch k+1 may not start before that of batch k is through (in a training loop
+            # the optimizer step sits between them): only the data-side work - sampling, kNN - runs ahead
+            prev_done = torch.cuda.Event()
+            prev_done.record(torch.cuda.current_stream())
+    return last

@@ -552,6 +552,46 @@ def test_scene_pass_scannet_config_three_rooms(P):
         np.testing.assert_allclose(_np(r["out"]), w["out"], rtol=1e-3, atol=1e-3)
 
 
+def test_batches_in_flight_give_what_single_passes_give(P):
+    """bench.py's timed loop: several batches in flight (pipeline.passes_in_flight - the sampling chains of the next
+    batches queued in front of this batch's index builds and attention blocks, one stream set and one state set per
+    lane).  Three DIFFERENT batches through three lanes, twice over: every tensor of every batch must be what the batch
+    gives in a pass of its own - integer tensors and the forward output bit-identical, and the gradients the backward
+    left in the lane's state tensors equal too (those summed with float atomics: to 1e-4)."""
+    from stratified_transformer_amd import pipeline, scene
+    cfg = pipeline.s3dis_config()
+    batches = [scene.make_batch(sz, seed=90 + i) for i, sz in enumerate(([6000, 5000], [7000], [4000, 4000, 3000]))]
+    xs = [dev(x) for x, _ in batches]
+    offs = [dev(o) for _, o in batches]
+    single, lanes = [], []
+    for i in range(3):
+        st, res = pipeline.scene_pass(xs[i], offs[i], cfg, seed=11)
+        torch.cuda.synchronize()
+        grads = [[t.grad.clone() for t in (s.q, s.k, s.v) + tuple(s.tables)] for s in st]
+        single.append((res, grads))
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            lane_states, _ = pipeline.scene_pass(xs[i], offs[i], cfg, seed=11, lane=i)
+        lanes.append((stream, lane_states))
+    torch.cuda.synchronize()
+    last = pipeline.passes_in_flight(xs, offs, cfg, lanes, 6)
+    torch.cuda.synchronize()
+    for i in range(3):
+        res, grads = single[i]
+        assert len(last[i]) == len(res)
+        for a, b in zip(res, last[i]):
+            assert torch.equal(a["downsample_idx"], b["downsample_idx"])
+            for name in ("even", "odd"):
+                for field in ("index_1", "offsets", "rel_idx"):
+                    assert torch.equal(getattr(a[name], field), getattr(b[name], field)), (i, a["stage"], name, field)
+            if "transition_knn" in a:
+                assert torch.equal(a["transition_knn"], b["transition_knn"])
+            assert torch.equal(a["out"], b["out"])
+        for s, want in zip(lanes[i][1], grads):
+            for t, w in zip((s.q, s.k, s.v) + tuple(s.tables), want):
+                torch.testing.assert_close(t.grad, w, rtol=1e-4, atol=1e-4)
+
+
 def test_full_size_batch_of_ten_rooms_properties(P):
     """BASELINE config 5 at full size (10 rooms x 100 000 points in one batch, > 1 M points): too large for the oracle,
     so the pass is checked through size-independent properties - every room of the batch gives exactly what it

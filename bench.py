@@ -129,12 +129,14 @@ def run_gpu(args, rank, world):
     barrier()
     # the optional fused module on the same passes: reported beside the headline, which stays on
     # the reference's operator API
-    pipeline.passes_in_flight([xyz], [offset], cfg, lanes, min(args.warmup, 2) or 1, fused=True)
-    barrier()
-    t2 = time.perf_counter()
-    pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=True)
-    barrier()
-    fused_elapsed = max_over_ranks(time.perf_counter() - t2)
+    fused_elapsed = None
+    if not args.no_fused:
+        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, min(args.warmup, 2) or 1, fused=True)
+        barrier()
+        t2 = time.perf_counter()
+        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=True)
+        barrier()
+        fused_elapsed = max_over_ranks(time.perf_counter() - t2)
     return dict(cfg=cfg, xyz_np=xyz_np, states=states, results=results, timer=timer, live=live, elapsed=elapsed, fused_elapsed=fused_elapsed,
                 single_elapsed=single_elapsed, inflight_same=bool(same), dev=dev)
 
@@ -163,8 +165,8 @@ def roofline(comp, run, among=None):
             launches = [dict(n=n, m=int(n * cfg.ratio) + 1) for n in ns[:-1]]
         bytes_per_launch = float(np.mean([algorithmic_bytes(name, l) for l in launches]))
         note = "mean over the op's launches in one step (one per stage); latency-bound: %d dependent iterations" % sum(l["m"] for l in launches)
-    elif name.startswith("knn/"):
-        bytes_per_launch = None
+    elif name.startswith("knn/") or algorithmic_bytes(name, info) is None:  # (an op without a byte model can only
+        bytes_per_launch = None                                              # dominate under a serializing profiler)
     else:
         # attention ops run depth times per stage; bytes are summed over all launches of a step / launches
         tot, cnt = 0, 0
@@ -178,7 +180,7 @@ def roofline(comp, run, among=None):
         note = "mean over the op's %d launches per step (all stages/blocks)" % cnt
     if bytes_per_launch is None:
         return dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
-                    note="kNN is VALU/latency-bound; see DESIGN.md")
+                    note="no byte model for this op (kNN is VALU/latency-bound; see DESIGN.md)")
     dur_s = comp[name]["ms_per_call"] / 1e3
     achieved = bytes_per_launch / dur_s / 1e9
     # HBM-side bytes per launch from the committed PMC passes (tools/pmc_traffic.py: separate FETCH_SIZE and
@@ -270,6 +272,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the fused-module leg (counter passes)")
     ap.add_argument("--in-flight", type=int, default=3, help="batches in flight (lanes); 1 = one batch at a time")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -301,7 +304,7 @@ def main():
             "single_batch": {"ms_per_step": round(run["single_elapsed"] / args.steps * 1e3, 3),
                              "value": round(N_POINTS * world / (run["single_elapsed"] / args.steps), 1),
                              "note": "the same K passes one batch at a time on the default stream (latency of a pass on its own) in this process, i.e. with GPU_MAX_HW_QUEUES=%s; with the runtime's default of 4 hardware queues a pass on its own takes ~38 ms (profiles/)" % os.environ.get("GPU_MAX_HW_QUEUES", "default")},
-            "fused_module": {"ms_per_step": round(run["fused_elapsed"] / args.steps * 1e3, 3),
+            "fused_module": None if run["fused_elapsed"] is None else {"ms_per_step": round(run["fused_elapsed"] / args.steps * 1e3, 3),
                              "note": "same timed loop with stratified_transformer_amd.fused.window_attention (fused logits+softmax forward, two-walk backward, one autograd node) instead of the five operators; not the headline"},
             "roofline": roofline(comp, run),
             "roofline_attention": roofline(comp, run, among="attn"),

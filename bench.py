@@ -62,7 +62,8 @@ def algorithmic_bytes(op, info):
 
 def run_gpu(args, rank, world):
     from stratified_transformer_amd import pipeline, scene
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    # (the modulo only matters for a rehearsal of the N>1 path with several ranks on a one-GPU box)
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
     cfg = pipeline.s3dis_config()
     xyz_np = scene.make_room(N_POINTS, seed=rank)
@@ -72,13 +73,14 @@ def run_gpu(args, rank, world):
     states, results = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + rank)  # creates resident tensors
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def max_over_ranks(seconds):
         if world > 1:
-            t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+            t = torch.tensor([seconds], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             return float(t.item())
         return seconds
@@ -279,7 +281,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl")
+        # RCCL; BENCH_DIST_BACKEND=gloo only to rehearse the N>1 code path with several ranks on one GPU
+        torch.distributed.init_process_group(os.environ.get("BENCH_DIST_BACKEND", "nccl"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     run = run_gpu(args, rank, world)

@@ -90,6 +90,7 @@ def run_gpu(args, rank, world):
     # queued in front of the index builds and attention blocks of batch k, the way a training loop prefetches its
     # data-side geometry; the forward+backward of consecutive batches stay strictly in order (an event between
     # them, where the optimizer step would sit).  Same kernels, same results as a pass on its own (checked below).
+    HOST_OFFS = [[N_POINTS]]  # (the host copy of the batch offsets a data loader has)
     lanes = []
     for li in range(args.in_flight):
         lane_stream = torch.cuda.Stream(dev)
@@ -99,14 +100,14 @@ def run_gpu(args, rank, world):
         lanes.append((lane_stream, lane_states))
     barrier()
     if args.warmup > 0:
-        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.warmup)
+        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.warmup, offset_host_list=HOST_OFFS)
     # In the timed region only the sampler launches (the dominant op, 7 per pass) carry event pairs; the
     # per-op table of all components comes from passes run again afterwards with events around every
     # op (~270 event records per pass are host work, and the late stages are close to host-bound).
     live = pipeline.Timer(True, only=("fps/",))
     barrier()
     t0 = time.perf_counter()
-    last = pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, timer=live)
+    last = pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, timer=live, offset_host_list=HOST_OFFS)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
@@ -133,10 +134,10 @@ def run_gpu(args, rank, world):
     # the reference's operator API
     fused_elapsed = None
     if not args.no_fused:
-        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, min(args.warmup, 2) or 1, fused=True)
+        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, min(args.warmup, 2) or 1, fused=True, offset_host_list=HOST_OFFS)
         barrier()
         t2 = time.perf_counter()
-        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=True)
+        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=True, offset_host_list=HOST_OFFS)
         barrier()
         fused_elapsed = max_over_ranks(time.perf_counter() - t2)
     return dict(cfg=cfg, xyz_np=xyz_np, states=states, results=results, timer=timer, live=live, elapsed=elapsed, fused_elapsed=fused_elapsed,

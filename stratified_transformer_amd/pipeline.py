@@ -162,7 +162,8 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
     raise RuntimeError("scene_pass_phases yielded twice")
 
 
-def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0):
+def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0,
+                      inputs_resident=False, offset_host=None):
     """Generator form of scene_pass: the first next() enqueues the geometry chain of ALL stages (no host sync in
     it) and yields; the second runs the index builds (which stop the host: key width, pair count) and the attention
     blocks, and returns (states, results) through StopIteration.  passes_in_flight puts the first phase of the next
@@ -188,11 +189,19 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     main = torch.cuda.current_stream(dev)
     geo = geometry_stream(dev, 3 * lane) if overlap else main
     knn_s = geometry_stream(dev, 3 * lane + 1) if overlap else main
-    if overlap:
+    if overlap and not inputs_resident:
+        # xyz / offset may have been produced on the current stream just now.  (inputs_resident: the caller vouches
+        # that they are complete - passes_in_flight - and the side streams need not wait for whatever the current
+        # stream still holds, i.e. the attention blocks of the lane's previous batch.)
         geo.wait_stream(main)
         knn_s.wait_stream(main)
         geometry_stream(dev, 3 * lane + 2).wait_stream(main)
-    offset_host = [int(o) for o in offset.tolist()]
+    # offset_host: the caller's host copy of `offset` (a data loader has it).  Without it the offsets are read back,
+    # which synchronises the current stream - with batches in flight that means waiting for the attention blocks of
+    # the lane's previous batch.
+    if offset_host is None:
+        offset_host = offset.tolist()
+    offset_host = [int(o) for o in offset_host]
     P.hint_host_offsets(offset, offset_host)
     make = states is None
     states = [] if make else states
@@ -211,10 +220,20 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     n_trans = (len(cfg.stages) - first - 1) + (0 if cfg.stem_transformer else 1)
     for _ in range(n_trans):
         plan_host.append(index_build.transition_down_offset(plan_host[-1], cfg.ratio))
-    plan_dev = [offset] + [_offsets_tensor(v, dev) for v in plan_host[1:]]
-    strat_dev = [_offsets_tensor(index_build.stratified_new_offset(v, cfg.downsample_scale), dev) for v in plan_host]
+    # They go through the index stream, which is idle by construction (the host has read every result of the lane's
+    # previous batch from it): a host-to-device copy from pageable memory blocks the host until the stream it was
+    # queued on reaches it; the lane's main stream may still hold the previous batch's blocks, its kNN stream the
+    # upsampling queries behind the whole sampling chain.  (Not a further stream: the runtime multiplexes streams onto
+    # hardware queues, and an upload stream that lands in a sampler's queue stops the host for the sampler's 27 ms.)
+    up_s = geometry_stream(dev, 3 * lane + 2) if overlap else main
+    with torch.cuda.stream(up_s):
+        plan_dev = [offset] + [_offsets_tensor(v, dev) for v in plan_host[1:]]
+        strat_dev = [_offsets_tensor(index_build.stratified_new_offset(v, cfg.downsample_scale), dev) for v in plan_host]
     if overlap:
-        geo.wait_stream(main)  # the uploads above were enqueued on the main stream
+        for s_ in (geo, knn_s, main):
+            s_.wait_stream(up_s)
+            for t in plan_dev[1:] + strat_dev:
+                t.record_stream(s_)
     level = [0]
 
     def transition(x, off, off_host):
@@ -328,10 +347,10 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     return states, results
 
 
-def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused=False):
+def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused=False, offset_host_list=None, paced=True):
     """`steps` passes, batch k on lane k % len(lanes); lanes = [(stream, states), ...], one set of resident state
     tensors per lane.  The geometry chains of the next len(lanes)-1 batches are queued in front of the index builds
-    and attention blocks of batch k (scene_pass_phases); nothing is shared between two lanes but the read-only inputs.  The caller synchronizes the device before and after.
+    and attention blocks of batch k (scene_pass_phases); nothing is shared between two lanes but the read-only inputs, which have to be complete (resident) when this is called.  The caller synchronizes the device before and after.
     Returns the results of the last pass of every lane."""
     last = [None] * len(lanes)
 
@@ -339,7 +358,8 @@ def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused
         stream, states = lanes[k % len(lanes)]
         with torch.cuda.stream(stream):
             gen = scene_pass_phases(xyz_list[k % len(xyz_list)], offset_list[k % len(offset_list)], cfg, states, timer,
-                                    fused=fused, lane=k % len(lanes))
+                                    fused=fused, lane=k % len(lanes), inputs_resident=True,
+                                    offset_host=None if offset_host_list is None else offset_host_list[k % len(offset_host_list)])
             next(gen)  # the geometry chain of batch k is queued
         return gen
 
@@ -348,6 +368,12 @@ def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused
     queue = [start(k) for k in range(min(ahead, steps))]
     for k in range(steps):
         if k + ahead < steps:
+            # Pacing: the geometry of batch k+ahead is released when batch k-1 is through, so a fixed number of
+            # sampling chains is in flight, evenly spaced.  Released as early as the host can (three chains start
+            # in a burst, slow each other and the attention kernels beside them) a step takes 28.5 instead of 24.8 ms;
+            # with the same dependency on the device only (side streams waiting for the lane's main stream) 26.9 ms.
+            if paced and prev_done is not None:
+                prev_done.synchronize()
             queue.append(start(k + ahead))
         gen = queue.pop(0)
         with torch.cuda.stream(lanes[k % len(lanes)][0]):

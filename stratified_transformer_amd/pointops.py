@@ -118,6 +118,7 @@ _HOST_OFFSETS = {}
 def hint_host_offsets(tensor, values):
     """Tell the sampler the host copy of a (device) offset tensor, so that it need not read it back
     (a D2H copy synchronises the stream, which defeats running the sampler beside other work)."""
+    _HOST_OFFSETS.pop((tensor.data_ptr(), tensor._version), None)  # (re-inserted at the young end)
     _HOST_OFFSETS[(tensor.data_ptr(), tensor._version)] = ([int(v) for v in values], tensor)
     while len(_HOST_OFFSETS) > 64:
         _HOST_OFFSETS.pop(next(iter(_HOST_OFFSETS)))

@@ -38,6 +38,7 @@
 //
 // Used for D = 16 and L <= 80 (all shipped configs) when a CSC view is set; otherwise rpe.hip's kernels run.
 #include "rpe_common.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace p2 {
@@ -195,11 +196,23 @@ struct TableGeo {
     static constexpr size_t lds_bytes() { return walk_bytes() > flush_bytes() ? walk_bytes() : flush_bytes(); }
 };
 
-template <int HG, int TA>
+// STAMP: diagnostic build only (P2_TG_STAMPS=1): cycle sums of the phases of every wave of workgroup 0 -> dbg
+template <int HG, int TA, bool STAMP = false>
 __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int h, int L, const float *__restrict__ w,
                                                                       const float *__restrict__ X, const int *__restrict__ offs,
                                                                       const int *__restrict__ pair_map, const int *__restrict__ rel,
-                                                                      float *__restrict__ grad_table) {
+                                                                      float *__restrict__ grad_table,
+                                                                      unsigned long long *__restrict__ dbg = nullptr) {
+    unsigned long long c_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+    auto stamp = [&](int ph) {  // everything issued so far has completed; the time since the last stamp goes to phase ph
+        if (STAMP) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            c_ph[ph] += t - t_last;
+            t_last = t;
+        }
+    };
+    if (STAMP) t_last = __builtin_amdgcn_s_memtime();
     constexpr int D = 16, NW = TG_WAVES;
     using G = TableGeo<HG, TA>;
     extern __shared__ float lds[];
@@ -230,6 +243,7 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
     const int rb = min(N, (int)blockIdx.x * per), re = min(N, rb + per);
     if (threadIdx.x == 0) next_row = rb;
     __syncthreads();
+    stamp(0);  // 0: prologue (zeroing the histograms)
     // A wave claims its next row, and requests that row's bounds, while it still works on the last segment of the
     // current one: the claim (an LDS round trip) and the bounds (a memory round trip) are off the dependent chain
     // of the segment that uses them.
@@ -277,6 +291,7 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
                     mreg[i] = pair_map ? pair_map[slot] : slot;
                 }
             }
+            stamp(1);  // 1: row bounds + pair ids
             if (last_segment) {  // wave-uniform; behind the pair ids so that the claim's LDS round trip overlaps them
                 nrow = claim();
                 if (nrow >= 0) {
@@ -291,6 +306,7 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
                     wreg[i] = w[(size_t)mreg[i] * h + h0 + min(c, hgn - 1)];
                 }
             }
+            stamp(2);  // 2: claim of the next row + rel indices, weights, X row
             unsigned mxb = 0u;
 #pragma unroll
             for (int i = 0; i < TG_MAXP; i++) {
@@ -317,8 +333,11 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
         } else if (lane < HG * 4) {
             *reinterpret_cast<float4 *>(&xs[(wave * HG + (lane >> 2)) * 16 + 4 * c]) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        stamp(3);  // 3: scale sweep + LDS atomics
         // the 12 histograms and X rows of the group are complete; stop when no wave had a segment
-        if (!__syncthreads_or(row >= 0)) break;
+        const int more = __syncthreads_or(row >= 0);
+        stamp(4);  // 4: waiting for the group's slowest wave
+        if (!more) break;
 #pragma unroll
         for (int i = 0; i < G::GPW; i++) {
             const int g = wave + i * NW;  // group = (head t, bin tile bt)
@@ -338,7 +357,9 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
                 }
             }
         }
+        stamp(5);  // 5: outer products
         __syncthreads();  // histograms are zero again, xs may be overwritten
+        stamp(6);  // 6: second barrier
     }
     // Flush.  C/D layout of 16x16x4: lane holds D[row = (lane>>4)*4 + reg][col = lane&15]  (row = bin, col = i).
     // In the [L, h, 16, 3] table the 48 floats of one (bin, head) are contiguous, and a wave owns all three axis
@@ -367,6 +388,11 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // reads done before the next group overwrites the stage
             }
         }
+    }
+    stamp(7);  // 7: flush
+    if (STAMP && dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) dbg[wave * 8 + i] = c_ph[i];
     }
 }
 
@@ -574,6 +600,23 @@ static void launch_table_grad(int N, int h, int L, const float *w, const float *
         const int groups = div_up(h, HG);
         using G = TableGeo<HG, TA>;
         const size_t lds = G::lds_bytes();
+        if (getenv("P2_TG_STAMPS")) {  // diagnostic only: synchronous, prints the phase cycles of workgroup 0 to stderr
+            unsigned long long *dbg = nullptr, host[TG_WAVES * 8];
+            (void)hipMalloc(&dbg, sizeof(host));
+            (void)hipMemset(dbg, 0, sizeof(host));
+            const int bx = walk_blocks(N, groups, TG_WAVES, 2);
+            hipLaunchKernelGGL((table_grad_kernel<HG, TA, true>), dim3(bx, groups), dim3(TG_WAVES * 64), lds, st, N, h, L, w, X, offs,
+                               pair_map, rel, grad_table, dbg);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+            (void)hipFree(dbg);
+            fprintf(stderr, "[tg stamps] N %d h %d blocks %d x %d %s: prologue ids relw atomics wait1 mfma wait2 flush (cycles)\n", N, h, bx, groups,
+                    pair_map ? "by key" : "by query");
+            for (int wv = 0; wv < TG_WAVES; wv += 5)
+                fprintf(stderr, "[tg stamps]   wave %2d: %llu %llu %llu %llu %llu %llu %llu %llu\n", wv, host[wv * 8], host[wv * 8 + 1],
+                        host[wv * 8 + 2], host[wv * 8 + 3], host[wv * 8 + 4], host[wv * 8 + 5], host[wv * 8 + 6], host[wv * 8 + 7]);
+            return;
+        }
         hipLaunchKernelGGL((table_grad_kernel<HG, TA>), dim3(walk_blocks(N, groups, TG_WAVES, 2), groups), dim3(TG_WAVES * 64), lds, st,
                            N, h, L, w, X, offs, pair_map, rel, grad_table);
     });

@@ -7,7 +7,11 @@
 One step = one pass of the hot path over one synthetic S3DIS-like scene of 100 000 points per GPU
 (stratified_transformer_amd/pipeline.py: for each of the 4 stages of s3dis_stratified_transformer.yaml
 the index build incl. stratified FPS, depth x [A1,A2,add,A3,A4] forward+backward, TransitionDown FPS +
-kNN(16), Upsample kNN(3)).  All inputs are resident in HBM before the timed region.  N>1: one process
+kNN(16), Upsample kNN(3)).  All inputs are resident in HBM before the timed region.  The K timed passes run with
+--in-flight L (default 3) batches in flight: the sampling chains of the next L-1 batches - functions of the
+coordinates alone - are queued ahead of this batch's index builds and attention blocks, forward+backward of
+consecutive batches strictly in order (pipeline.passes_in_flight); the same K passes one at a time are reported
+as `single_batch`, and `same_results_as_single_pass` says that both give the same tensors.  N>1: one process
 per GPU, one scene per rank (scenes are independent units: windows never cross a batch element, so the
 path shards with no data-path collective) -> weak scaling; value = all ranks' points / max-over-ranks time.
 

@@ -1,5 +1,6 @@
 // Shared plumbing of libpointops2_hip.so (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -57,7 +58,18 @@ inline bool check_launch() {
 // Only worth it for small problems (`small`): kernels that fill the chip on their own gain nothing and lose a
 // little to the extra events (stage 0 of the S3DIS config: A1 backward 377 -> 424 us; stages 2-3: -4 %).
 // P2_NO_FORK=1 keeps every kernel on the caller's stream.
-inline bool fork_worthwhile(int64_t pair_heads) { return pair_heads < 7000000; }
+// The gain exists only with the runtime's default of 4 hardware queues (where side streams mostly share a queue and
+// the fork is a cheap reordering): with GPU_MAX_HW_QUEUES=24 - which batches in flight need, DESIGN.md 5 - the forked
+// kernels truly run side by side and every one of them gets slower (stage-2 block 775 -> 1007 us, stage 3 704 -> 920),
+// so the launchers then keep to the caller's stream.  P2_FORK_MAX=<pair-heads> overrides the limit.
+inline bool fork_worthwhile(int64_t pair_heads) {
+    static const int64_t limit = [] {
+        if (const char *e = getenv("P2_FORK_MAX")) return (int64_t)atoll(e);
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        return (q && atoi(q) > 4) ? (int64_t)0 : (int64_t)7000000;
+    }();
+    return pair_heads < limit;
+}
 class ForkJoin {
   public:
     ForkJoin(hipStream_t main, bool small);

@@ -8,7 +8,7 @@ One step = one pass of the hot path over one synthetic S3DIS-like scene of 100 0
 (stratified_transformer_amd/pipeline.py: for each of the 4 stages of s3dis_stratified_transformer.yaml
 the index build incl. stratified FPS, depth x [A1,A2,add,A3,A4] forward+backward, TransitionDown FPS +
 kNN(16), Upsample kNN(3)).  All inputs are resident in HBM before the timed region.  The K timed passes run with
---in-flight L (default 3) batches in flight: the sampling chains of the next L-1 batches - functions of the
+--in-flight L (default 3-5, by the length of the run) batches in flight: the sampling chains of the next L-1 batches - functions of the
 coordinates alone - are queued ahead of this batch's index builds and attention blocks, forward+backward of
 consecutive batches strictly in order (pipeline.passes_in_flight); the same K passes one at a time are reported
 as `single_batch`, and `same_results_as_single_pass` says that both give the same tensors.  N>1: one process
@@ -280,8 +280,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused-module leg (counter passes)")
-    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight (lanes); 1 = one batch at a time")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="batches in flight (lanes); 1 = one batch at a time; 0 = by the length of the run: a deeper pipeline "
+                         "has a higher steady-state rate (24 steps: 24.0 / 23.0 / 21.8 ms per step with 3 / 4 / 5 lanes) but the "
+                         "timed region starts with an empty one, and filling it costs more (5 steps: 24.7 / 25.7 / 26.9 ms)")
     args = ap.parse_args()
+    if args.in_flight <= 0:
+        args.in_flight = 3 if args.steps < 8 else 4 if args.steps < 16 else 5
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     if world > 1:

@@ -106,13 +106,16 @@ __global__ __launch_bounds__(BS) void knn_grid_kernel(int m, int k, const float 
                                                       const KnnPlan *__restrict__ plan, const int *__restrict__ cell_start,
                                                       const float4 *__restrict__ rec, int *__restrict__ idx,
                                                       float *__restrict__ dist2, int *__restrict__ replay,
-                                                      int *__restrict__ replay_count) {
+                                                      int *__restrict__ replay_count, const int *__restrict__ qperm) {
     extern __shared__ float smem[];
     float *ld = smem;                                           // [k+1][BS] ascending (d2, index)
     int *li = reinterpret_cast<int *>(smem + (size_t)(k + 1) * BS);
     const int tid = threadIdx.x;
-    const int pt = blockIdx.x * BS + tid;
-    if (pt >= m) return;
+    if (blockIdx.x * BS + tid >= m) return;
+    // queries are taken in CELL order (qperm: the queries sorted by their own grid cell): the 64 queries of a wave
+    // then walk the same few cells - the same cell_start entries and candidate records, similar trip counts -
+    // instead of 64 unrelated neighbourhoods (FPS order scatters consecutive samples over the whole cloud)
+    const int pt = qperm[blockIdx.x * BS + tid];
     int bt = 0;
     while (!(pt < new_offset[bt])) bt++;
     const int start = bt == 0 ? 0 : offset[bt - 1];
@@ -265,7 +268,8 @@ static size_t knn_cub_bytes(int n, int b) {
 }
 static size_t knn_ws_bytes(int n, int m, int b) {
     return al(sizeof(KnnPlan)) + al((size_t)b * 24) + 4 * al((size_t)n * 4) + al((size_t)n * 16) +
-           al(((size_t)KNN_CELL_CAP * b + 1) * 4) + al((size_t)m * 4) + al(256) + al(knn_cub_bytes(n, b));
+           al(((size_t)KNN_CELL_CAP * b + 1) * 4) + al((size_t)m * 4) + al(256) + 4 * al((size_t)m * 4) +
+           al(knn_cub_bytes(max(n, m), b));
 }
 
 // returns false when the grid path does not apply (caller runs the full scan)
@@ -287,6 +291,10 @@ bool knn_grid_launch(int m, int k, int n, int b, const float *xyz, const float *
     int *cell_start = (int *)p; p += al(((size_t)KNN_CELL_CAP * b + 1) * 4);
     int *replay = (int *)p; p += al((size_t)m * 4);
     int *replay_count = (int *)p; p += al(256);
+    unsigned *qkeys_in = (unsigned *)p; p += al((size_t)m * 4);
+    unsigned *qkeys_out = (unsigned *)p; p += al((size_t)m * 4);
+    int *qvals_in = (int *)p; p += al((size_t)m * 4);
+    int *qperm = (int *)p; p += al((size_t)m * 4);
     void *cub_tmp = p;
     size_t cub_bytes = w.bytes - (size_t)(p - reinterpret_cast<char *>(w.ptr));
 
@@ -298,10 +306,15 @@ bool knn_grid_launch(int m, int k, int n, int b, const float *xyz, const float *
                                                       n, 0, bits_for_cells(b), st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return true; }
     hipLaunchKernelGGL(knn_finish_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, b, keys_out, vals_out, xyz, plan, cell_start, rec);
+    // the queries in cell order (same grid, same key as the candidates)
+    hipLaunchKernelGGL(knn_cell_kernel, dim3(div_up(m, 256)), dim3(256), 0, st, m, b, new_xyz, new_offset, plan, qkeys_in, qvals_in);
+    e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, (const unsigned *)qkeys_in, qkeys_out, (const int *)qvals_in, qperm, m, 0,
+                                           bits_for_cells(b), st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return true; }
     constexpr int BS = 64;
     const size_t lds = (size_t)(k + 1) * BS * 8;
     hipLaunchKernelGGL(knn_grid_kernel<BS>, dim3(div_up(m, BS)), dim3(BS), lds, st, m, k, new_xyz, offset, new_offset, plan, cell_start, rec,
-                       idx, dist2, replay, replay_count);
+                       idx, dist2, replay, replay_count, qperm);
     hipLaunchKernelGGL(knn_replay_kernel, dim3(min(div_up(m, 64), 1024)), dim3(64), (size_t)k * 64 * 8, st, k, replay, replay_count, xyz, new_xyz,
                        offset, new_offset, idx, dist2);
     return true;

@@ -140,12 +140,18 @@ __global__ __launch_bounds__(BS) void knn_grid_kernel(int m, int k, const float 
                 const int y = cy + dy;
                 if (y < 0 || y >= p.dims[1]) continue;
                 const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-                const int step = face ? 1 : max(2 * r, 1);  // interior rows of the shell: only the two x-ends
-                for (int dx = -r; dx <= r; dx += step) {
-                    const int x = cx + dx;
-                    if (x < 0 || x >= p.dims[0]) continue;
-                    const int cell = base + (z * p.dims[1] + y) * p.dims[0] + x;
-                    const int s = cell_start[cell], e = cell_start[cell + 1];
+                // A face row of the shell is the whole x-run [cx-r, cx+r]: its cells are consecutive cell ids, so
+                // their candidates are ONE contiguous range of records (two cell_start reads instead of 2r+1 dependent
+                // pairs).  An interior row contributes only its two x-ends.  The order in which candidates are seen
+                // does not matter: the list is ordered by (distance, index), exact ties are replayed.
+                const int row = base + (z * p.dims[1] + y) * p.dims[0];
+                const int nseg = (face || r == 0) ? 1 : 2;
+                for (int seg = 0; seg < nseg; seg++) {
+                    int x0, x1;
+                    if (face || r == 0) { x0 = max(cx - r, 0); x1 = min(cx + r, p.dims[0] - 1); }
+                    else { x0 = x1 = seg == 0 ? cx - r : cx + r; }
+                    if (x0 < 0 || x1 >= p.dims[0] || x0 > x1) continue;
+                    const int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
                     for (int t = s; t < e; t++) {
                         const float4 c = rec[t];
                         const float ddx = qx - c.x, ddy = qy - c.y, ddz = qz - c.z;

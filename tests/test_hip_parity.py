@@ -50,7 +50,9 @@ def _check_attention_ops(P, p, use_csc=True):
         out.backward(dev(p["go_pairs"]))
         gq, gk = ref.attention_step1_v2_backward(p["go_pairs"], p["q"], p["k"], p["index_1"], p["offsets"])
         np.testing.assert_allclose(_np(q.grad), gq, **TOL)
-        np.testing.assert_allclose(_np(k.grad), gk, **TOL)
+        # without a CSC grad_k is summed with float atomics in arbitrary order (as the reference sums it): a sum of ~50
+        # terms of size ~5 is then only good to a few ulp of the total (seen once: 2.7e-5 on a 4.45), well inside the 1e-3 bar
+        np.testing.assert_allclose(_np(k.grad), gk, **(TOL if use_csc else TTOL))
         # A2
         q, k, tq, tk = _leaf(p["q"]), _leaf(p["k"]), _leaf(p["table_q"]), _leaf(p["table_k"])
         out = P.dot_prod_with_idx_v3(q, offs, n_max, k, i1, tq, tk, rel)
@@ -59,7 +61,7 @@ def _check_attention_ops(P, p, use_csc=True):
         out.backward(dev(p["go_pairs"]))
         gq, gk, gtq, gtk = ref.dot_prod_with_idx_v3_backward(p["go_pairs"], *args)
         np.testing.assert_allclose(_np(q.grad), gq, **TOL)
-        np.testing.assert_allclose(_np(k.grad), gk, **TOL)
+        np.testing.assert_allclose(_np(k.grad), gk, **(TOL if use_csc else TTOL))
         np.testing.assert_allclose(_np(tq.grad), gtq, **TTOL)
         np.testing.assert_allclose(_np(tk.grad), gtk, **TTOL)
         # A3

@@ -11,6 +11,7 @@ Linear layers (qkv/proj/MLP) are not part of the unit.
 """
 from dataclasses import dataclass, field
 
+import os
 import torch
 
 from . import index_build
@@ -364,6 +365,8 @@ def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused
         return gen
 
     prev_done = None
+    done_events = []
+    pace_lag = int(os.environ.get("P2_PACE_LAG", "1"))  # released on batch k-lag: 22.2 / 24.0 / 28.8 ms per step for 1 / 2 / 3
     ahead = len(lanes) - 1  # geometry phases queued in front of the attention phase being enqueued
     queue = [start(k) for k in range(min(ahead, steps))]
     for k in range(steps):
@@ -372,8 +375,8 @@ def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused
             # sampling chains is in flight, evenly spaced.  Released as early as the host can (three chains start
             # in a burst, slow each other and the attention kernels beside them) a step takes 28.5 instead of 24.8 ms;
             # with the same dependency on the device only (side streams waiting for the lane's main stream) 26.9 ms.
-            if paced and prev_done is not None:
-                prev_done.synchronize()
+            if paced and len(done_events) >= pace_lag:
+                done_events[-pace_lag].synchronize()
             queue.append(start(k + ahead))
         gen = queue.pop(0)
         with torch.cuda.stream(lanes[k % len(lanes)][0]):
@@ -386,4 +389,5 @@ def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused
             # the optimizer step sits between them): only the data-side work - sampling, kNN - runs ahead
             prev_done = torch.cuda.Event()
             prev_done.record(torch.cuda.current_stream())
+            done_events.append(prev_done)
     return last

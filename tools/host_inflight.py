@@ -9,13 +9,14 @@ cfg = pipeline.s3dis_config()
 xyz = torch.from_numpy(scene.make_room(100000, 0)).cuda()
 off = torch.tensor([100000], dtype=torch.int32, device="cuda")
 lanes = []
-for li in range(3):
+NL = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+for li in range(NL):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         st, _ = pipeline.scene_pass(xyz, off, cfg, lane=li)
     lanes.append((s, st))
 torch.cuda.synchronize()
-pipeline.passes_in_flight([xyz], [off], cfg, lanes, 3)
+pipeline.passes_in_flight([xyz], [off], cfg, lanes, NL, offset_host_list=[[100000]])
 torch.cuda.synchronize()
 marks = []
 calls = []

@@ -234,6 +234,54 @@ void window_attention_backward_launcher(int N, int M, int h, int hdim, const flo
                                         const int *rel_idx, float *grad_logit, float *grad_q, float *grad_k, float *grad_v,
                                         float *grad_table_q, float *grad_table_k, float *grad_table_v);
 
+/* ---- window-centric ("cell") attention: SURVEY 8f-1, second step ------------------------------------------------
+ * A cell = the queries of one (small window, large window) intersection of a block pattern; they share one candidate key
+ * list (the small window's points, then the sampled points of the large window), so a cell is a dense n_q x n_k tile of
+ * pairs (model/stratified_transformer.py:15-18, :20-38).  The plan of a pattern is built from the arrays the index build
+ * already has (window partitions, bucketed samples, window coordinates):
+ *   pass 1  pointops2_cell_plan_count_launcher  cells, their order, sizes and scans; counts[4] = {cells, tile entries P,
+ *           key slots K, largest key count} (device; the caller reads P and K to allocate the arrays of pass 2)
+ *   pass 2  pointops2_cell_plan_fill_launcher   key list per cell, owner cell per key slot, and per tile entry the packed
+ *           rel-pos index r0 | r1 << 8 | r2 << 16 (model :186-190, clamped to [0, L)) with bit 31 set where the candidate is
+ *           NOT a key of that query (same window coordinate, :34)
+ * All arrays are caller-allocated device memory: cell_order, qcell, cell_perm [N]; cell_desc [4N]; cell_qstart, cell_kbase,
+ * cell_pbase [N+2]; counts [4]; cell_keys, kcell [K]; relp [P]. */
+typedef struct pointops2_cell_plan {
+    int n_points;            /* N */
+    int n_pairs;             /* P = sum over cells of n_q * n_k (host copy of counts[1]) */
+    int n_keyslots;          /* K = sum over cells of n_k       (host copy of counts[2]) */
+    const int *counts;       /* device [4] */
+    const int *cell_perm;    /* [N]   cell ids, largest tile first (first counts[0] entries) */
+    const int *cell_qstart;  /* [N+2] first sorted query position of a cell */
+    const int *cell_kbase;   /* [N+2] first key slot of a cell */
+    const int *cell_pbase;   /* [N+2] first tile entry of a cell; entry (il, jl) is at pbase + il * n_k + jl */
+    const int *cell_order;   /* [N]   query (point) ids grouped by cell, ascending inside a cell */
+    const int *qcell;        /* [N]   cell of a sorted query position */
+    const int *cell_keys;    /* [K]   key (point) ids per cell: dense keys ascending, then stratified candidates ascending */
+    const int *kcell;        /* [K]   cell of a key slot */
+    const unsigned int *relp;/* [P]   packed rel-pos index + "not a key" flag */
+} pointops2_cell_plan;
+size_t pointops2_cell_plan_workspace_bytes(int N);
+void pointops2_cell_plan_count_launcher(int N, const int *s_cluster, const int *s_starts, const int *l_cluster,
+                                        const int *ls_starts, int *cell_order, int *qcell, int *cell_desc, int *cell_qstart,
+                                        int *cell_kbase, int *cell_pbase, int *cell_perm, int *counts, void *ws, size_t ws_bytes);
+void pointops2_cell_plan_fill_launcher(int N, const float *xyz, float window, float quant, int L, const int *s_order, const int *ls,
+                                       const float *wc, const int *cell_order, const int *qcell, const int *cell_qstart,
+                                       const int *cell_desc, const int *cell_kbase, const int *cell_pbase, int *cell_keys, int *kcell,
+                                       unsigned int *relp);
+/* The whole operator sequence of WindowAttention.forward (:183-208) on a cell plan, d = 16.  q, k, v [N,h,16]; tables [L,h,16,3];
+ * out [N,h,16] fully written; pbuf [h, P] receives the softmax weights in tile order (kept for the backward); ml [N,h,2] is
+ * scratch (running max / sum of rows longer than one register chunk). */
+void cell_attention_forward_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const float *q, const float *k,
+                                     const float *v, const float *table_q, const float *table_k, const float *table_v, float *out,
+                                     float *ml, float *pbuf);
+/* Its backward.  out / pbuf = the forward's; gsbuf [h, P] scratch (receives the logit gradients in tile order); grad_q fully
+ * written; grad_k, grad_v and the three table gradients are ACCUMULATED (zero-fill them).  L <= 80. */
+void cell_attention_backward_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const float *grad_out, const float *q,
+                                      const float *k, const float *v, const float *out, const float *table_q, const float *table_k,
+                                      const float *table_v, const float *pbuf, float *gsbuf, float *grad_q, float *grad_k,
+                                      float *grad_v, float *grad_table_q, float *grad_table_k, float *grad_table_v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,10 @@ SIGNATURES = {
     "pointops2_sampled_buckets_launcher": [I, I, P, P, P, P, P, P, P, P, Z],
     "pointops2_pairs_count_launcher": [I, P, P, P, P, P, P, P, P, Z],
     "pointops2_pairs_fill_launcher": [I, P, F, F, P, P, P, P, P, P, P, P, P, P, P],
+    "pointops2_cell_plan_count_launcher": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, Z],
+    "pointops2_cell_plan_fill_launcher": [I, P, F, F, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    "cell_attention_forward_launcher": [P, I, I, I] + [P] * 9,
+    "cell_attention_backward_launcher": [P, I, I, I] + [P] * 16,
 }
 # entry points with a non-void result
 RESULTS = {
@@ -72,6 +76,7 @@ RESULTS = {
     "pointops2_fps_workspace_bytes": ([I, I], Z),
     "pointops2_knn_workspace_bytes": ([I, I, I], Z),
     "pointops2_index_workspace_bytes": ([I], Z),
+    "pointops2_cell_plan_workspace_bytes": ([I], Z),
 }
 
 

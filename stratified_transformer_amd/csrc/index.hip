@@ -199,6 +199,111 @@ __global__ __launch_bounds__(256) void pairs_fill_kernel(int N, const float *__r
     }
 }
 
+
+// ---- cells: the window-centric view of a pair list (cell_attn.hip) -------------------
+// All queries with the same (small window, large window) share their candidate key list: the small window's
+// bucket (dense keys) followed by the sampled points of the large window's bucket (stratified candidates);
+// a candidate is a key of query i iff its fp32 floor-div window coordinate differs from i's - the very
+// predicate of pairs_fill_kernel, evaluated per (query, candidate) and stored as a flag.  A cell is therefore a
+// dense n_q x n_k tile: the attention kernels load a cell's key rows once instead of once per query.
+__global__ void cell_key_kernel(int N, int lbits, const int *__restrict__ s_cluster, const int *__restrict__ l_cluster,
+                                unsigned long long *__restrict__ keys, int *__restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    keys[i] = ((unsigned long long)(unsigned)s_cluster[i] << lbits) | (unsigned)l_cluster[i];
+    vals[i] = i;
+}
+// cell id of every sorted position; per cell: first sorted position, descriptor {dense start, dense count,
+// candidate start, candidate count}, key count and tile size (for the scans)
+__global__ void cell_describe_kernel(int N, const int *__restrict__ order, const int *__restrict__ flags, const int *__restrict__ rank_incl,
+                                     const int *__restrict__ s_cluster, const int *__restrict__ s_starts,
+                                     const int *__restrict__ l_cluster, const int *__restrict__ ls_starts, int *__restrict__ qcell,
+                                     int *__restrict__ cell_qstart, int *__restrict__ cell_desc, int *__restrict__ nk_of,
+                                     int *__restrict__ counts) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const int cid = rank_incl[t] - 1;
+    qcell[t] = cid;
+    if (flags[t]) {
+        const int i = order[t];
+        const int ws = s_cluster[i], wl = l_cluster[i];
+        const int d0 = s_starts[ws], nd = s_starts[ws + 1] - d0;
+        const int c0 = ls_starts[wl], ns = ls_starts[wl + 1] - c0;
+        cell_qstart[cid] = t;
+        cell_desc[cid * 4 + 0] = d0;
+        cell_desc[cid * 4 + 1] = nd;
+        cell_desc[cid * 4 + 2] = c0;
+        cell_desc[cid * 4 + 3] = ns;
+        nk_of[cid] = nd + ns;
+        atomicMax(&counts[3], nd + ns);
+    }
+    if (t == N - 1) {
+        cell_qstart[cid + 1] = N;
+        counts[0] = cid + 1;
+    }
+}
+// tile sizes n_q * n_k (0 past the last cell) and the work-order sort keys (largest tile first)
+__global__ void cell_tile_kernel(int N, const int *__restrict__ counts, const int *__restrict__ cell_qstart, int *__restrict__ nk_of,
+                                 int *__restrict__ tile_of, unsigned *__restrict__ work_key, int *__restrict__ ids) {
+    const int cid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cid > N) return;
+    const int nC = counts[0];
+    int nk = 0, tile = 0;
+    if (cid < nC) {
+        nk = nk_of[cid];
+        tile = (cell_qstart[cid + 1] - cell_qstart[cid]) * nk;
+    }
+    nk_of[cid] = nk;
+    tile_of[cid] = tile;
+    if (cid < N) {
+        work_key[cid] = 0xffffffffu - (unsigned)tile;
+        ids[cid] = cid;
+    }
+}
+__global__ void cell_totals_kernel(int N, const int *__restrict__ cell_kbase, const int *__restrict__ cell_pbase, int *__restrict__ counts) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        counts[1] = cell_pbase[N];  // pair slots (tile entries) of all cells
+        counts[2] = cell_kbase[N];  // key slots of all cells
+    }
+}
+// one wave per sorted query position: its row of the cell's tile = packed rel-pos index (r0 | r1 << 8 | r2 << 16) of
+// every candidate key, bit 31 set where the candidate is not a key of this query; the wave of a cell's first query
+// also writes the cell's key list
+__global__ __launch_bounds__(256) void cell_fill_kernel(int N, const float *__restrict__ xyz, float two_w, float quant, int L,
+                                                        const int *__restrict__ s_order, const int *__restrict__ ls,
+                                                        const float *__restrict__ wc, const int *__restrict__ order,
+                                                        const int *__restrict__ qcell, const int *__restrict__ cell_qstart,
+                                                        const int *__restrict__ cell_desc, const int *__restrict__ cell_kbase,
+                                                        const int *__restrict__ cell_pbase, int *__restrict__ cell_keys,
+                                                        int *__restrict__ kcell, unsigned *__restrict__ relp) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= N) return;
+    const int cid = qcell[t], i = order[t];
+    const int d0 = cell_desc[cid * 4], nd = cell_desc[cid * 4 + 1], c0 = cell_desc[cid * 4 + 2], ns = cell_desc[cid * 4 + 3];
+    const int nk = nd + ns, il = t - cell_qstart[cid], kb = cell_kbase[cid];
+    unsigned *row = relp + (size_t)cell_pbase[cid] + (size_t)il * nk;
+    const float inv = __fdiv_rn(1.0f, 100000.0f);
+    const float xi[3] = {xyz[(size_t)i * 3], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2]};
+    for (int jl = lane; jl < nk; jl += 64) {
+        const int j = jl < nd ? s_order[d0 + jl] : ls[c0 + jl - nd];
+        unsigned w = (jl >= nd && !coord_differs(wc, i, j)) ? 0x80000000u : 0u;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {  // the arithmetic of write_pair
+            float r = __fsub_rn(xi[a], xyz[(size_t)j * 3 + a]);
+            r = __fmul_rn(rintf(__fmul_rn(r, 100000.0f)), inv);
+            r = __fsub_rn(__fadd_rn(r, two_w), 0.0001f);
+            const int b = min(max((int)div_floor(r, quant), 0), L - 1);  // the model asserts 0 <= . < L (:189-190)
+            w |= (unsigned)b << (8 * a);
+        }
+        row[jl] = w;
+        if (il == 0) {
+            cell_keys[kb + jl] = j;
+            kcell[kb + jl] = cid;
+        }
+    }
+}
+
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t sort64_bytes(int N) {
     size_t bytes = 0;
@@ -312,6 +417,72 @@ void pointops2_pairs_fill_launcher(int N, const float *xyz, float window, float 
     const float two_w = (float)(2.0 * (double)window);
     hipLaunchKernelGGL(pairs_fill_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, xyz, two_w, quant, s_cluster, s_order, s_starts,
                        l_cluster, ls, ls_starts, wc, offsets, index_0, index_1, rel_idx);
+    check_launch();
+}
+
+
+// ---- cells (see cell_key_kernel) ------------------------------------------------------------------------------
+size_t pointops2_cell_plan_workspace_bytes(int N) {
+    if (N <= 0) return 0;
+    return 2 * al((size_t)N * 8) + 6 * al(((size_t)N + 2) * 4) + al(sort64_bytes(N)) + al(scan_bytes(N + 2));
+}
+
+// pass 1 (no host sync needed before it): cells of one block pattern from its small / large partitions and the
+// bucketed samples.  All outputs caller-allocated: cell_order, qcell, cell_perm [N]; cell_desc [4N]; cell_qstart,
+// cell_kbase, cell_pbase [N+2]; counts [4] = {cells, tile entries P, key slots K, largest key count}.
+void pointops2_cell_plan_count_launcher(int N, const int *s_cluster, const int *s_starts, const int *l_cluster,
+                                        const int *ls_starts, int *cell_order, int *qcell, int *cell_desc, int *cell_qstart,
+                                        int *cell_kbase, int *cell_pbase, int *cell_perm, int *counts, void *ws, size_t ws_bytes) {
+    if (N <= 0) return;
+    if (ws_bytes < pointops2_cell_plan_workspace_bytes(N)) { set_error("pointops2_cell_plan_count: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    char *p = reinterpret_cast<char *>(ws);
+    unsigned long long *keys_in = (unsigned long long *)p; p += al((size_t)N * 8);
+    unsigned long long *keys_out = (unsigned long long *)p; p += al((size_t)N * 8);
+    int *vals_in = (int *)p; p += al(((size_t)N + 2) * 4);
+    int *flags = (int *)p; p += al(((size_t)N + 2) * 4);
+    int *rank = (int *)p; p += al(((size_t)N + 2) * 4);
+    int *nk_of = (int *)p; p += al(((size_t)N + 2) * 4);
+    int *tile_of = (int *)p; p += al(((size_t)N + 2) * 4);
+    unsigned *work_key = (unsigned *)p; p += al(((size_t)N + 2) * 4);
+    void *tmp = p;
+    size_t tmp_bytes = ws_bytes - (size_t)(p - reinterpret_cast<char *>(ws));
+    const int g = div_up(N, 256);
+    int lbits = 1;
+    while ((1ll << lbits) <= (long long)N) lbits++;  // window ids are < N
+    (void)hipMemsetAsync(counts, 0, 4 * sizeof(int), st);
+    hipLaunchKernelGGL(cell_key_kernel, dim3(g), dim3(256), 0, st, N, lbits, s_cluster, l_cluster, keys_in, vals_in);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const unsigned long long *)keys_in, keys_out, (const int *)vals_in,
+                                                      cell_order, N, 0, 2 * lbits, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(boundary_flag_kernel, dim3(g), dim3(256), 0, st, N, keys_out, flags);
+    e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, N, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(cell_describe_kernel, dim3(g), dim3(256), 0, st, N, cell_order, flags, rank, s_cluster, s_starts, l_cluster, ls_starts,
+                       qcell, cell_qstart, cell_desc, nk_of, counts);
+    // (vals_in is free again: the ids of the work-order sort)
+    hipLaunchKernelGGL(cell_tile_kernel, dim3(div_up(N + 1, 256)), dim3(256), 0, st, N, counts, cell_qstart, nk_of, tile_of, work_key, vals_in);
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, (const int *)nk_of, cell_kbase, N + 1, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, (const int *)tile_of, cell_pbase, N + 1, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const unsigned *)work_key, (unsigned *)keys_out, (const int *)vals_in, cell_perm, N,
+                                           0, 32, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(cell_totals_kernel, dim3(1), dim3(64), 0, st, N, cell_kbase, cell_pbase, counts);
+    check_launch();
+}
+
+// pass 2 (the caller has read counts and allocated cell_keys / kcell [K] and relp [P]): key lists and packed rel-pos tiles
+void pointops2_cell_plan_fill_launcher(int N, const float *xyz, float window, float quant, int L, const int *s_order, const int *ls,
+                                       const float *wc, const int *cell_order, const int *qcell, const int *cell_qstart,
+                                       const int *cell_desc, const int *cell_kbase, const int *cell_pbase, int *cell_keys, int *kcell,
+                                       unsigned *relp) {
+    if (N <= 0) return;
+    if (L < 1 || L > 255) { set_error("pointops2_cell_plan_fill: table rows L must be in 1..255 (packed rel-pos index)"); return; }
+    const float two_w = (float)(2.0 * (double)window);
+    hipLaunchKernelGGL(cell_fill_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, xyz, two_w, quant, L, s_order, ls, wc, cell_order,
+                       qcell, cell_qstart, cell_desc, cell_kbase, cell_pbase, cell_keys, kcell, relp);
     check_launch();
 }
 

@@ -94,3 +94,57 @@ def window_attention(q, k, v, table_q, table_k, table_v, index0_offsets, index1,
     """q, k, v [N, h, 16] f32 (q already scaled, as the model does at :181); tables [L, h, 16, 3]; the block's CSR
     pair list (index0_offsets [N+1], index1 [M] i32) and rel_idx [M, 3] i32  ->  [N, h, 16]"""
     return WindowAttention.apply(q, k, v, table_q, table_k, table_v, index0_offsets, index1, rel_idx)
+
+
+class CellAttention(Function):
+    """The same operator sequence on a cell plan (index_build.CellPlan; csrc/cell_attn.hip): one wave per
+    (cell, head) loads the cell's key / value rows once for all its queries; the backward keeps dK / dV of a cell in
+    registers and takes the three table gradients from cell-ordered softmax weights / logit gradients."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, table_q, table_k, table_v, plan):
+        N, h, hdim = q.shape
+        if hdim != 16:
+            raise RuntimeError("cell_attention: d != 16 (use the operators of pointops for other head dims)")
+        L = table_q.shape[0]
+        if plan.n_points != N or k.shape[0] != N or v.shape[0] != N:
+            raise RuntimeError("cell_attention: the plan was built for %d points, q/k/v have %d/%d/%d rows" % (plan.n_points, N, k.shape[0], v.shape[0]))
+        if L > plan.table_rows:
+            raise RuntimeError("cell_attention: the plan's rel-pos indices were clamped to %d rows, the tables have %d" % (plan.table_rows, L))
+        pointops_cuda._chk((q, torch.float32, "q"), (k, torch.float32, "k"), (v, torch.float32, "v"),
+                           (table_q, torch.float32, "table_q"), (table_k, torch.float32, "table_k"), (table_v, torch.float32, "table_v"))
+        assert table_k.shape == table_q.shape and table_v.shape == table_q.shape
+        dev = q.device
+        out = torch.empty((N, h, hdim), dtype=torch.float32, device=dev)
+        ml = torch.empty((N, h, 2), dtype=torch.float32, device=dev)
+        pbuf = torch.empty((h, max(plan.n_pairs, 1)), dtype=torch.float32, device=dev)
+        _lib.call("cell_attention_forward_launcher", plan.c_arg(), h, hdim, L, ptr(q), ptr(k), ptr(v), ptr(table_q), ptr(table_k), ptr(table_v),
+                  ptr(out), ptr(ml), ptr(pbuf), device=dev)
+        ctx.plan = plan
+        ctx.save_for_backward(q, k, v, table_q, table_k, table_v, out, pbuf)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, table_q, table_k, table_v, out, pbuf = ctx.saved_tensors
+        plan = ctx.plan
+        N, h, hdim = q.shape
+        L = table_q.shape[0]
+        dev = q.device
+        grad_out = grad_out.contiguous()
+        pointops_cuda._chk((grad_out, torch.float32, "grad_out"))
+        gsbuf = torch.empty_like(pbuf)
+        grad_q = torch.empty_like(q)
+        grad_k, grad_v = torch.zeros_like(k), torch.zeros_like(v)
+        gtq, gtk, gtv = torch.zeros_like(table_q), torch.zeros_like(table_k), torch.zeros_like(table_v)
+        _lib.call("cell_attention_backward_launcher", plan.c_arg(), h, hdim, L, ptr(grad_out), ptr(q), ptr(k), ptr(v), ptr(out), ptr(table_q),
+                  ptr(table_k), ptr(table_v), ptr(pbuf), ptr(gsbuf), ptr(grad_q), ptr(grad_k), ptr(grad_v), ptr(gtq), ptr(gtk), ptr(gtv),
+                  device=dev)
+        return grad_q, grad_k, grad_v, gtq, gtk, gtv, None
+
+
+def cell_attention(q, k, v, table_q, table_k, table_v, plan):
+    """q, k, v [N, h, 16] f32 (q already scaled, :181); tables [L, h, 16, 3]; plan = BlockIndex.cells of the block's
+    pattern (index_build.stage_index_hip(..., cell_table_rows=L))  ->  [N, h, 16], same numbers as the five operators
+    up to the order of the sums."""
+    return CellAttention.apply(q, k, v, table_q, table_k, table_v, plan)

@@ -97,10 +97,14 @@ class Timer:
         return out
 
 
+def table_rows(st):
+    return 2 * int((2 * st.window_size + 1e-4) // st.quant_size)  # model/stratified_transformer.py:142,145
+
+
 def make_stage_state(xyz, offset, st, seed):
     g = torch.Generator(device=xyz.device).manual_seed(seed)
     n, h, d = xyz.shape[0], st.num_heads, st.channels // st.num_heads
-    L = 2 * int((2 * st.window_size + 1e-4) // st.quant_size)  # model/stratified_transformer.py:142,145
+    L = table_rows(st)
 
     def rn(*shape, scale=1.0):
         return (torch.randn(*shape, generator=g, device=xyz.device) * scale).requires_grad_(True)
@@ -118,6 +122,11 @@ def attention_block(state, blk, timer, fused=False):
     tq, tk, tv = state.tables
     for t in (q, k, v, tq, tk, tv):
         t.grad = None
+    if fused == "cell":
+        from . import fused as F
+        out = timer.run("attn_fwd/cell", F.cell_attention, q, k, v, tq, tk, tv, blk.cells)
+        timer.run("attn_bwd", out.backward, state.grad_out)
+        return out
     if fused:
         from . import fused as F
         out = timer.run("attn_fwd/fused", F.window_attention, q, k, v, tq, tk, tv, blk.offsets, blk.index_1, blk.rel_idx)
@@ -152,9 +161,9 @@ def geometry_stream(device, which=0):
     return _GEO_STREAMS[key]
 
 
-def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0):
+def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0, cells=False):
     """Runs the whole unit once (both phases of scene_pass_phases back to back).  Returns (states, results)."""
-    gen = scene_pass_phases(xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane)
+    gen = scene_pass_phases(xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane, cells=cells)
     next(gen)
     try:
         next(gen)
@@ -164,7 +173,7 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
 
 
 def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0,
-                      inputs_resident=False, offset_host=None):
+                      inputs_resident=False, offset_host=None, cells=False):
     """Generator form of scene_pass: the first next() enqueues the geometry chain of ALL stages (no host sync in
     it) and yields; the second runs the index builds (which stop the host: key width, pair count) and the attention
     blocks, and returns (states, results) through StopIteration.  passes_in_flight puts the first phase of the next
@@ -288,7 +297,8 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
                 t.record_stream(idx_s)
         with torch.cuda.stream(idx_s):
             if use_hip_index:
-                even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds)
+                even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds,
+                                         table_rows(st) if (cells or fused == "cell") else None)
             else:
                 parts = timer.run("index/partition", index_build.stage_partitions, x, off, st.window_size)
                 even = timer.run("index/pairs", index_build.build_block_index, x, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)

@@ -681,3 +681,93 @@ def test_fused_window_attention_matches_the_operator_chain(P, case):
                             + ref.dot_prod_with_idx_v3(p["q"], p["offsets"], p["k"], p["index_1"], p["table_q"], p["table_k"], p["rel_idx"]), p["offsets"])
     want = ref.attention_step2_with_rel_pos_value_v2(r, p["v"], p["offsets"], p["index_1"], p["table_v"], p["rel_idx"])
     np.testing.assert_allclose(_np(out_b), want, rtol=2e-5, atol=1e-4)
+
+
+# ---- window-centric ("cell") attention: csrc/index.hip cells + csrc/cell_attn.hip ----------------------
+def _cell_scene(n, nbatch, w, quant, seed, L):
+    from stratified_transformer_amd import index_build, scene
+    sizes = [n // nbatch + (1 if i < n % nbatch else 0) for i in range(nbatch)]
+    xyz_np, offset = scene.make_batch(sizes, seed=seed)
+    rng = np.random.default_rng(seed)
+    ds = np.sort(rng.permutation(n)[: n // 8 + nbatch]).astype(np.int32)
+    even, odd, _ = index_build.stage_index_hip(dev(xyz_np), dev(offset), w, quant, dev(ds), cell_table_rows=L)
+    return xyz_np, offset, even, odd
+
+
+def _expand_cells(plan):
+    """the pair list a cell plan stands for, in (query, tile order): arrays (query, key, r0, r1, r2)"""
+    nC = plan.n_cells
+    qstart, kbase, pbase = (_np(t) for t in (plan.cell_qstart, plan.cell_kbase, plan.cell_pbase))
+    order, keys, relp = _np(plan.cell_order), _np(plan.cell_keys), _np(plan.relp).view(np.uint32)
+    rows = []
+    for c in range(nC):
+        nq, nk = qstart[c + 1] - qstart[c], kbase[c + 1] - kbase[c]
+        tile = relp[pbase[c]: pbase[c] + nq * nk].reshape(nq, nk)
+        qi = np.repeat(order[qstart[c]: qstart[c + 1]], nk).reshape(nq, nk)
+        kj = np.tile(keys[kbase[c]: kbase[c + 1]], nq).reshape(nq, nk)
+        keep = (tile >> 31) == 0
+        rows.append(np.stack([qi[keep], kj[keep], tile[keep] & 255, (tile[keep] >> 8) & 255, (tile[keep] >> 16) & 255], 1))
+    allp = np.concatenate(rows).astype(np.int64)
+    return allp[np.argsort(allp[:, 0], kind="stable")]
+
+
+@pytest.mark.parametrize("n,nbatch,w,quant", [(6000, 1, 0.16, 0.01), (5000, 3, 0.32, 0.02), (900, 2, 0.64, 0.04)])
+def test_cell_plan_is_the_pair_list(n, nbatch, w, quant):
+    """Every (query, key, rel-pos index) of the CSR pair list - itself bit-identical to the oracle's restatement of
+    get_indice_pairs (test_index_build_hip_matches_oracle_and_torch_path) - appears exactly once in the cell tiles, in the
+    same per-query order; each query and each cell id exactly once; the work order is a permutation, largest tile first."""
+    L = 2 * int((2 * w + 1e-4) // quant)
+    _, _, even, odd = _cell_scene(n, nbatch, w, quant, seed=n, L=L)
+    for blk in (even, odd):
+        plan = blk.cells
+        got = _expand_cells(plan)
+        i0, i1, rel = _np(blk.index_0).astype(np.int64), _np(blk.index_1).astype(np.int64), np.clip(_np(blk.rel_idx), 0, L - 1)
+        assert got.shape[0] == i0.shape[0]
+        assert np.array_equal(got[:, 0], i0) and np.array_equal(got[:, 1], i1) and np.array_equal(got[:, 2:], rel)
+        assert np.array_equal(np.sort(_np(plan.cell_order)), np.arange(n))
+        perm = _np(plan.cell_perm)[: plan.n_cells]
+        assert np.array_equal(np.sort(perm), np.arange(plan.n_cells))
+        tiles = np.diff(_np(plan.cell_pbase)[: plan.n_cells + 1])
+        assert np.all(np.diff(tiles[perm]) <= 0) and tiles.sum() == plan.n_pairs
+        assert np.diff(_np(plan.cell_kbase)[: plan.n_cells + 1]).max() == plan.nk_max
+
+
+def _oracle_attention(p, i1, offs, rel, go):
+    sm = ref.segment_softmax(ref.attention_step1_v2(p["q"], p["k"], i1, offs)
+                             + ref.dot_prod_with_idx_v3(p["q"], offs, p["k"], i1, p["table_q"], p["table_k"], rel), offs)
+    out = ref.attention_step2_with_rel_pos_value_v2(sm, p["v"], offs, i1, p["table_v"], rel)
+    ga, gv, gtv = ref.attention_step2_with_rel_pos_value_v2_backward(go, sm, p["v"], offs, i1, p["table_v"], rel)
+    gs = ref.segment_softmax_backward(sm, ga, offs)
+    gq1, gk1 = ref.attention_step1_v2_backward(gs, p["q"], p["k"], i1, offs)
+    gq2, gk2, gtq, gtk = ref.dot_prod_with_idx_v3_backward(gs, p["q"], offs, p["k"], i1, p["table_q"], p["table_k"], rel)
+    return out, dict(q=gq1 + gq2, k=gk1 + gk2, v=gv, table_q=gtq, table_k=gtk, table_v=gtv)
+
+
+@pytest.mark.parametrize("case", ["s3dis_stage0_h3", "batch3_h6_L64", "scannet_L80_h3", "big_cells_two_chunks_h2", "coarse_h12"])
+def test_cell_attention_matches_the_oracle(case):
+    """fused.cell_attention (forward and all six gradients) against the oracle's operator chain on the CSR pair list of the
+    same block pattern, even and odd.  Tolerance: the north_star's 1e-3 is the bar; measured differences are ~1e-6."""
+    from stratified_transformer_amd import fused
+    n, nbatch, w, quant, h = dict(s3dis_stage0_h3=(5000, 1, 0.16, 0.01, 3), batch3_h6_L64=(4000, 3, 0.32, 0.02, 6),
+                                  scannet_L80_h3=(4000, 1, 0.1, 0.005, 3), big_cells_two_chunks_h2=(3000, 1, 0.32, 0.02, 2),
+                                  coarse_h12=(700, 2, 0.64, 0.04, 12))[case]
+    L = 2 * int((2 * w + 1e-4) // quant)
+    xyz_np, offset, even, odd = _cell_scene(n, nbatch, w, quant, seed=7 + h, L=L)
+    rng = np.random.default_rng(h)
+    p = dict(q=rng.standard_normal((n, h, 16), dtype=np.float32), k=rng.standard_normal((n, h, 16), dtype=np.float32),
+             v=rng.standard_normal((n, h, 16), dtype=np.float32))
+    for t in ("table_q", "table_k", "table_v"):
+        p[t] = rng.standard_normal((L, h, 16, 3), dtype=np.float32) * 0.5
+    go = rng.standard_normal((n, h, 16), dtype=np.float32)
+    for blk in (even, odd):
+        if case == "big_cells_two_chunks_h2":
+            assert blk.cells.nk_max > 128, blk.cells.nk_max  # more keys than one register chunk holds
+        leaves = {x: _leaf(p[x]) for x in ("q", "k", "v", "table_q", "table_k", "table_v")}
+        out = fused.cell_attention(*leaves.values(), blk.cells)
+        out.backward(dev(go))
+        want, grads = _oracle_attention(p, _np(blk.index_1), _np(blk.offsets), np.clip(_np(blk.rel_idx), 0, L - 1).astype(np.int32), go)
+        np.testing.assert_allclose(_np(out), want, rtol=2e-5, atol=1e-4)
+        for name, leaf in leaves.items():
+            tol = TTOL if name.startswith("table") else dict(rtol=2e-5, atol=2e-4)
+            scale = max(1.0, float(np.abs(grads[name]).max())) if name.startswith("table") else 1.0
+            np.testing.assert_allclose(_np(leaf.grad) / scale, grads[name] / scale, err_msg=f"{case} grad {name}", **tol)

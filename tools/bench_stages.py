@@ -20,7 +20,7 @@ def main():
     cfg = pipeline.s3dis_config()
     xyz = torch.from_numpy(scene.make_room(N, 0)).cuda()
     off = torch.tensor([N], dtype=torch.int32, device='cuda')
-    states, results = pipeline.scene_pass(xyz, off, cfg)
+    states, results = pipeline.scene_pass(xyz, off, cfg, cells=True)
     torch.cuda.synchronize()
     total = {}
     for si, (s, r) in enumerate(zip(states, results)):
@@ -54,6 +54,13 @@ def main():
         res['FUSEDf'] = timeit(lambda: fused.window_attention(q, k, v, tq, tk, tv, b.offsets, b.index_1, b.rel_idx))
         res['FUSEDb'] = timeit(lambda: bwd(fo, s.grad_out))
         res['ops_f'], res['ops_b'] = fwd_sum, bwd_sum
+        for pat in ('even', 'odd'):
+            plan = r[pat].cells
+            co = fused.cell_attention(q, k, v, tq, tk, tv, plan)
+            res['CELLf_' + pat] = timeit(lambda: fused.cell_attention(q, k, v, tq, tk, tv, plan))
+            res['CELLb_' + pat] = timeit(lambda: bwd(co, s.grad_out))
+        print('   cells even/odd', r['even'].cells.n_cells, r['odd'].cells.n_cells, 'P', r['even'].cells.n_pairs, r['odd'].cells.n_pairs,
+              'nk_max', r['even'].cells.nk_max, r['odd'].cells.nk_max)
         print('stage', si, 'N', s.xyz.shape[0], 'M', M, 'h', st.num_heads, 'L', tq.shape[0], 'depth', st.depth,
               {k_: round(v_) for k_, v_ in res.items()}, 'block us', round(tot), 'stage ms', round(tot * st.depth / 1e3, 2))
         for k_, v_ in res.items():

@@ -239,18 +239,22 @@ void window_attention_backward_launcher(int N, int M, int h, int hdim, const flo
  * list (the small window's points, then the sampled points of the large window), so a cell is a dense n_q x n_k tile of
  * pairs (model/stratified_transformer.py:15-18, :20-38).  The plan of a pattern is built from the arrays the index build
  * already has (window partitions, bucketed samples, window coordinates):
- *   pass 1  pointops2_cell_plan_count_launcher  cells, their order, sizes and scans; counts[4] = {cells, tile entries P,
- *           key slots K, largest key count} (device; the caller reads P and K to allocate the arrays of pass 2)
+ *   pass 1  pointops2_cell_plan_count_launcher  cells, their order, sizes and scans; counts[8] = {cells, tile entries P,
+ *           key slots K, largest key count, parents (cells before the cut)} (device; the caller reads P and K to allocate the arrays of pass 2);
+ *           max_queries > 0 cuts every cell into pieces of at most that many queries (a piece = one wave's unit of work)
  *   pass 2  pointops2_cell_plan_fill_launcher   key list per cell, owner cell per key slot, and per tile entry the packed
  *           rel-pos index r0 | r1 << 8 | r2 << 16 (model :186-190, clamped to [0, L)) with bit 31 set where the candidate is
  *           NOT a key of that query (same window coordinate, :34)
  * All arrays are caller-allocated device memory: cell_order, qcell, cell_perm [N]; cell_desc [4N]; cell_qstart, cell_kbase,
- * cell_pbase [N+2]; counts [4]; cell_keys, kcell [K]; relp [P]. */
+ * cell_pbase, parent_first [N+2]; counts [8]; cell_keys, kcell [K]; relp [P]. */
 typedef struct pointops2_cell_plan {
     int n_points;            /* N */
+    int n_cells;             /* host copy of counts[0] */
+    int n_parents;           /* host copy of counts[4]: cells before the cut into pieces of max_queries */
     int n_pairs;             /* P = sum over cells of n_q * n_k (host copy of counts[1]) */
     int n_keyslots;          /* K = sum over cells of n_k       (host copy of counts[2]) */
-    const int *counts;       /* device [4] */
+    const int *counts;       /* device [8] */
+    const int *parent_first; /* [N+2] first piece (cell id) of a parent; pieces of a parent are consecutive, their tiles contiguous */
     const int *cell_perm;    /* [N]   cell ids, largest tile first (first counts[0] entries) */
     const int *cell_qstart;  /* [N+2] first sorted query position of a cell */
     const int *cell_kbase;   /* [N+2] first key slot of a cell */
@@ -262,9 +266,10 @@ typedef struct pointops2_cell_plan {
     const unsigned int *relp;/* [P]   packed rel-pos index + "not a key" flag */
 } pointops2_cell_plan;
 size_t pointops2_cell_plan_workspace_bytes(int N);
-void pointops2_cell_plan_count_launcher(int N, const int *s_cluster, const int *s_starts, const int *l_cluster,
+void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_cluster, const int *s_starts, const int *l_cluster,
                                         const int *ls_starts, int *cell_order, int *qcell, int *cell_desc, int *cell_qstart,
-                                        int *cell_kbase, int *cell_pbase, int *cell_perm, int *counts, void *ws, size_t ws_bytes);
+                                        int *cell_kbase, int *cell_pbase, int *cell_perm, int *parent_first, int *counts, void *ws,
+                                        size_t ws_bytes);
 void pointops2_cell_plan_fill_launcher(int N, const float *xyz, float window, float quant, int L, const int *s_order, const int *ls,
                                        const float *wc, const int *cell_order, const int *qcell, const int *cell_qstart,
                                        const int *cell_desc, const int *cell_kbase, const int *cell_pbase, int *cell_keys, int *kcell,

@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpointops2_hip.so")
+LIB_PATH = os.environ.get("P2_LIB_PATH") or os.path.join(_HERE, "lib", "libpointops2_hip.so")  # (P2_LIB_PATH: kernel experiments)
 CSRC = os.path.join(_HERE, "csrc")
 _lib = None
 
@@ -62,7 +62,7 @@ SIGNATURES = {
     "pointops2_sampled_buckets_launcher": [I, I, P, P, P, P, P, P, P, P, Z],
     "pointops2_pairs_count_launcher": [I, P, P, P, P, P, P, P, P, Z],
     "pointops2_pairs_fill_launcher": [I, P, F, F, P, P, P, P, P, P, P, P, P, P, P],
-    "pointops2_cell_plan_count_launcher": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, Z],
+    "pointops2_cell_plan_count_launcher": [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z],
     "pointops2_cell_plan_fill_launcher": [I, P, F, F, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "cell_attention_forward_launcher": [P, I, I, I] + [P] * 9,
     "cell_attention_backward_launcher": [P, I, I, I] + [P] * 16,

@@ -29,8 +29,13 @@ namespace p2 {
 
 typedef float __attribute__((ext_vector_type(4))) f32x4c;
 
-constexpr int CA_NP = 8;      // passes of 16 keys a lane keeps in registers: 128 keys per chunk
-constexpr int CA_WAVES = 12;  // waves per workgroup (one head's three tables in LDS per workgroup)
+constexpr int CA_NP = 8;      // forward: passes of 16 keys a lane keeps in registers (128 keys per chunk)
+constexpr int CA_NP_BWD = 3;  // backward: 48 keys per chunk (key rows AND their gradient accumulators in registers; chunks simply add up)
+#ifndef CA_WAVES_OVERRIDE
+#define CA_WAVES_OVERRIDE 12
+#endif
+constexpr int CA_WAVES = CA_WAVES_OVERRIDE;  // waves per workgroup (one head's three tables in LDS per workgroup)
+constexpr int CA_WAVES_BWD = 12;             // backward workgroup
 
 // ---- cross-lane sums without LDS round trips where the hardware has a lane network for it ----
 template <int CTRL>
@@ -72,6 +77,63 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {
 __device__ __forceinline__ unsigned bload_u32(rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
 __device__ __forceinline__ float bload_f32(rsrc_t r, int off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
 __device__ __forceinline__ void bstore_f32(rsrc_t r, int off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0); }
+// N consecutive dwords per lane as ONE (N <= 4) or two vector-memory instructions: the walkers below are bound by the
+// number of memory instructions a CU can issue, not by bytes
+typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3c __attribute__((ext_vector_type(3)));
+typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+template <int N>
+__device__ __forceinline__ void bload_words(rsrc_t r, int off, unsigned (&w)[N]) {
+    static_assert(N == 2 || N == 3 || N == 4 || N == 6 || N == 8, "pass counts of dispatch_passes");
+    if constexpr (N == 2) {
+        const u32x2c a = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        w[0] = a.x; w[1] = a.y;
+    } else if constexpr (N == 3) {
+        const u32x3c a = __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 0);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z;
+    } else {
+        const u32x4c a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        if constexpr (N == 6) {
+            const u32x2c b = __builtin_amdgcn_raw_buffer_load_b64(r, off + 16, 0, 0);
+            w[4] = b.x; w[5] = b.y;
+        } else if constexpr (N == 8) {
+            const u32x4c b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0);
+            w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void bload_floats(rsrc_t r, int off, float (&f)[N]) {
+    unsigned w[N];
+    bload_words<N>(r, off, w);
+#pragma unroll
+    for (int t = 0; t < N; t++) f[t] = __uint_as_float(w[t]);
+}
+// stores the first `nvalid` of a lane's N floats (a lane whose slots are all inside the row: one or two wide stores;
+// the one lane that straddles the row's end: dword stores, so that the next row's entries stay intact)
+template <int N>
+__device__ __forceinline__ void bstore_floats(rsrc_t r, int off, const float (&f)[N], int nvalid) {
+    if (nvalid >= N) {
+        if constexpr (N == 2) {
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2c{__float_as_uint(f[0]), __float_as_uint(f[1])}, r, off, 0, 0);
+        } else if constexpr (N == 3) {
+            __builtin_amdgcn_raw_buffer_store_b96(u32x3c{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2])}, r, off, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4c{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])}, r,
+                                                   off, 0, 0);
+            if constexpr (N == 6)
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2c{__float_as_uint(f[4]), __float_as_uint(f[5])}, r, off + 16, 0, 0);
+            else if constexpr (N == 8)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4c{__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7])},
+                                                       r, off + 16, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < N; t++)
+            if (t < nvalid) bstore_f32(r, off + 4 * t, f[t]);
+    }
+}
 
 // ---- LDS image of a head's three tables: table TB at float offset TB * TS (TS a compile-time constant, so that the
 // three tables of one (axis, row) differ by an immediate offset), inside a table [axis][row][16] ----
@@ -97,6 +159,42 @@ __device__ __forceinline__ float4 tsum_at(const float *lds, RowOff r) {
                 *reinterpret_cast<const float4 *>(lds + OFF + r.o2));
 }
 
+// the three rows (one per axis) of one table for one pair, requested together
+struct Rows3 {
+    float4 a, b, c;
+};
+template <int OFF>
+__device__ __forceinline__ Rows3 rows_at(const float *lds, RowOff r) {
+    Rows3 x;
+    x.a = *reinterpret_cast<const float4 *>(lds + OFF + r.o0);
+    x.b = *reinterpret_cast<const float4 *>(lds + OFF + r.o1);
+    x.c = *reinterpret_cast<const float4 *>(lds + OFF + r.o2);
+    return x;
+}
+// T(m)[4c..4c+3] = tab[r0,.,.,0] + tab[r1,.,.,1] + tab[r2,.,.,2]   (left to right, as the reference), as packed
+// two-float adds (v_pk_add_f32: two lanes' worth of fp32 adds per instruction slot)
+typedef float f32x2c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 padd4(float4 a, float4 b) {
+    const f32x2c lo = f32x2c{a.x, a.y} + f32x2c{b.x, b.y}, hi = f32x2c{a.z, a.w} + f32x2c{b.z, b.w};
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ float4 pfma4(float s, float4 a, float4 acc) {
+    const f32x2c ss = f32x2c{s, s};
+    const f32x2c lo = __builtin_elementwise_fma(ss, f32x2c{a.x, a.y}, f32x2c{acc.x, acc.y});
+    const f32x2c hi = __builtin_elementwise_fma(ss, f32x2c{a.z, a.w}, f32x2c{acc.z, acc.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ float4 rsum(Rows3 r) { return padd4(padd4(r.a, r.b), r.c); }
+// <a, b> over this lane's four floats with packed multiply-adds (the two halves are summed at the end)
+__device__ __forceinline__ f32x2c pdot_acc(float4 a, float4 b, f32x2c acc) {
+    acc = __builtin_elementwise_fma(f32x2c{a.x, a.y}, f32x2c{b.x, b.y}, acc);
+    return __builtin_elementwise_fma(f32x2c{a.z, a.w}, f32x2c{b.z, b.w}, acc);
+}
+__device__ __forceinline__ float pdot4(float4 a, float4 b) {
+    const f32x2c r = pdot_acc(a, b, f32x2c{0.f, 0.f});
+    return r.x + r.y;
+}
+
 struct CellTask {
     int qs, nq, kb, nk, pbase;
 };
@@ -111,10 +209,173 @@ __device__ __forceinline__ CellTask cell_task(const pointops2_cell_plan &pl, int
     t.pbase = __builtin_amdgcn_readfirstlane(pl.cell_pbase[cell]);
     return t;
 }
+// Tasks are sorted by decreasing tile size and dealt to the resident waves in boustrophedon order (round r forwards,
+// round r+1 backwards), so that no wave collects the largest task of every round.
+__device__ __forceinline__ int snake_task(int round, int slot, int slots) { return round * slots + ((round & 1) ? slots - 1 - slot : slot); }
+
+// A chunk of a cell has np = 1..NP passes of 16 keys (wave-uniform).  The sweeps are straight-line code for a fixed
+// number of passes - the table rows of pass t+1 are requested before pass t is consumed, which a per-pass branch
+// would forbid (each pass a basic block of its own, every LDS round trip exposed) - instantiated for 2, 3, 4, 6 and 8
+// passes; a chunk runs the smallest instance that holds it (slots past its end are masked anyway).
+template <int NPMAX, typename F>
+__device__ __forceinline__ void dispatch_passes(int np, F f) {
+    if (np <= 2) f(std::integral_constant<int, 2>{});
+    else if (np == 3) f(std::integral_constant<int, 3>{});
+    else if (np == 4 || NPMAX <= 4) f(std::integral_constant<int, 4>{});
+    else if constexpr (NPMAX > 4) {
+        if (np <= 6) f(std::integral_constant<int, 6>{});
+        else f(std::integral_constant<int, 8>{});
+    }
+}
+
+struct LaneCtx {
+    const float *lds;
+    int L, lane, p, c, head, h, C, hoff;
+};
+struct CellBufs {
+    rsrc_t rel, key, qid;
+};
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// Key slots: lane (p, c) of an NPA-pass instance owns the NPA CONSECUTIVE keys j0 + p * NPA + t, t < NPA, of the chunk, so
+// that its rel-pos words, softmax weights and logit gradients of one query are NPA consecutive dwords = one wide load.
+// Query ids: 64 at a time, one per lane; a query's id is then a v_readlane away (a scalar: the q row address is uniform).
+template <int NPA>
+__device__ __forceinline__ void load_key_rows(const LaneCtx &x, const CellBufs &cb, const float *__restrict__ rows, int j0, float4 (&r4)[NPA]) {
+    unsigned keys[NPA];
+    bload_words<NPA>(cb.key, (j0 + x.p * NPA) * 4, keys);  // (past the end: key 0, never used)
+#pragma unroll
+    for (int t = 0; t < NPA; t++) r4[t] = ldg4(rows + (size_t)keys[t] * x.C + x.hoff);
+}
+
+template <int NPA, int TS>
+__device__ __forceinline__ void fwd_sweep_logits(const LaneCtx &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p,
+                                                 const float *__restrict__ q, const float *__restrict__ k, float *__restrict__ ml,
+                                                 int ch, bool single, int j0, int nkc) {
+    const int p = x.p, c = x.c;
+    const int nvalid = min(max(nkc - p * NPA, 0), NPA);  // this lane's slots inside the chunk
+    float4 k4[NPA];
+    load_key_rows<NPA>(x, cb, k, j0, k4);
+    // the inputs of query il+1 are requested while query il is worked on
+    int ids = (int)bload_u32(cb.qid, x.lane * 4);
+    int i_nx = __builtin_amdgcn_readlane(ids, 0);
+    float4 q4_nx = ldg4(q + (size_t)i_nx * x.C + x.hoff);
+    unsigned w_nx[NPA];
+    bload_words<NPA>(cb.rel, (j0 + p * NPA) * 4, w_nx);
+    for (int il = 0; il < ct.nq; il++) {
+        const int i = i_nx;
+        const float4 q4 = q4_nx;
+        unsigned w[NPA];
+#pragma unroll
+        for (int t = 0; t < NPA; t++) w[t] = w_nx[t];
+        const int roff = (il * ct.nk + j0 + p * NPA) * 4;
+        if (((il + 1) & 63) == 0) ids = (int)bload_u32(cb.qid, (il + 1 + x.lane) * 4);
+        i_nx = __builtin_amdgcn_readlane(ids, (il + 1) & 63);  // (past the end: query 0, never used)
+        q4_nx = ldg4(q + (size_t)i_nx * x.C + x.hoff);
+        bload_words<NPA>(cb.rel, roff + ct.nk * 4, w_nx);
+        float lg[NPA];
+        float mx = -INFINITY;
+        RowOff ro = row_off(w[0], x.L, c);
+        Rows3 rq = rows_at<0>(x.lds, ro), rk = rows_at<TS>(x.lds, ro);
+#pragma unroll
+        for (int t = 0; t < NPA; t++) {
+            Rows3 rq1 = rq, rk1 = rk;
+            if (t + 1 < NPA) {
+                ro = row_off(w[t + 1], x.L, c);
+                rq1 = rows_at<0>(x.lds, ro);
+                rk1 = rows_at<TS>(x.lds, ro);
+            }
+            const f32x2c d2 = pdot_acc(k4[t], rsum(rk), pdot_acc(q4, rsum(rq), pdot_acc(q4, k4[t], f32x2c{0.f, 0.f})));
+            const float s = quad_sum(d2.x + d2.y);
+            lg[t] = (t < nvalid && !(w[t] >> 31)) ? s : -INFINITY;
+            mx = fmaxf(mx, lg[t]);
+            rq = rq1;
+            rk = rk1;
+            __builtin_amdgcn_sched_barrier(0);  // at most two passes' table rows in flight (register budget)
+        }
+        mx = slots_max16(mx);
+        if (single) {
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NPA; t++) {
+                lg[t] = __expf(lg[t] - mx);  // exp(-inf) = 0: flagged entries and slots past the end
+                sum += lg[t];
+            }
+            const float inv = 1.0f / slots_sum16(sum);
+#pragma unroll
+            for (int t = 0; t < NPA; t++) lg[t] *= inv;
+            if (c == 0) bstore_floats<NPA>(rs_p, roff, lg, nvalid);
+        } else {
+            float *st = ml + ((size_t)i * x.h + x.head) * 2;
+            const float m_old = ch ? st[0] : -INFINITY, l_old = ch ? st[1] : 0.f;
+            const float m_new = fmaxf(m_old, mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NPA; t++) sum += __expf(lg[t] - m_new);
+            if (c == 0) bstore_floats<NPA>(rs_p, roff, lg, nvalid);  // logits; the second sweep makes them weights
+            sum = slots_sum16(sum);
+            if (x.lane == 0) {
+                st[0] = m_new;
+                st[1] = (m_old == -INFINITY ? 0.f : l_old * __expf(m_old - m_new)) + sum;
+            }
+        }
+    }
+}
+
+template <int NPA, int TS>
+__device__ __forceinline__ void fwd_sweep_values(const LaneCtx &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p,
+                                                 const float *__restrict__ v, const float *__restrict__ ml, float *__restrict__ out,
+                                                 int ch, bool single, int j0, int nkc) {
+    const int p = x.p, c = x.c;
+    const int nvalid = min(max(nkc - p * NPA, 0), NPA);
+    float4 v4[NPA];
+    load_key_rows<NPA>(x, cb, v, j0, v4);
+    unsigned w_nx[NPA];
+    float a_nx[NPA];
+    bload_words<NPA>(cb.rel, (j0 + p * NPA) * 4, w_nx);
+    bload_floats<NPA>(rs_p, (j0 + p * NPA) * 4, a_nx);
+    int ids = (int)bload_u32(cb.qid, x.lane * 4);
+    for (int il = 0; il < ct.nq; il++) {
+        if (il && (il & 63) == 0) ids = (int)bload_u32(cb.qid, (il + x.lane) * 4);
+        const int i = __builtin_amdgcn_readlane(ids, il & 63);
+        const int roff = (il * ct.nk + j0 + p * NPA) * 4;
+        unsigned w[NPA];
+        float a[NPA];
+#pragma unroll
+        for (int t = 0; t < NPA; t++) {
+            w[t] = w_nx[t];
+            a[t] = a_nx[t];
+        }
+        bload_words<NPA>(cb.rel, roff + ct.nk * 4, w_nx);
+        bload_floats<NPA>(rs_p, roff + ct.nk * 4, a_nx);
+        if (!single) {
+            const float *st = ml + ((size_t)i * x.h + x.head) * 2;
+            const float m = st[0], inv = 1.0f / st[1];
+#pragma unroll
+            for (int t = 0; t < NPA; t++) a[t] = __expf(a[t] - m) * inv;
+            if (c == 0) bstore_floats<NPA>(rs_p, roff, a, nvalid);
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        Rows3 rv = rows_at<2 * TS>(x.lds, row_off(w[0], x.L, c));
+#pragma unroll
+        for (int t = 0; t < NPA; t++) {
+            Rows3 rv1 = rv;
+            if (t + 1 < NPA) rv1 = rows_at<2 * TS>(x.lds, row_off(w[t + 1], x.L, c));
+            const float at = t < nvalid ? a[t] : 0.f;  // (a flagged entry's weight is stored as 0)
+            acc = pfma4(at, padd4(rsum(rv), v4[t]), acc);
+            rv = rv1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 tot = slots_sum16_4(acc);
+        if (p == 0) {
+            float *o = out + (size_t)i * x.C + x.hoff;
+            stg4(o, ch ? add4(tot, ldg4(o)) : tot);
+        }
+    }
+}
+
 template <int NP, int LCAP>
 __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ q,
                                                                  const float *__restrict__ k, const float *__restrict__ v,
@@ -123,180 +384,190 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_
                                                                  float *__restrict__ ml, float *__restrict__ pbuf, size_t plane) {
     constexpr int D = 16, TS = TabGeo<LCAP>::TS;
     extern __shared__ float lds[];
-    const int head = blockIdx.y, C = h * D;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, p = lane >> 2, c = lane & 3;
-    stage_table<D>(lds, table_q, L, h, head, 1);
-    stage_table<D>(lds + TS, table_k, L, h, head, 1);
-    stage_table<D>(lds + 2 * TS, table_v, L, h, head, 1);
+    LaneCtx x;
+    x.lds = lds;
+    x.L = L;
+    x.h = h;
+    x.head = blockIdx.y;
+    x.C = h * D;
+    x.lane = threadIdx.x & 63;
+    x.p = x.lane >> 2;
+    x.c = x.lane & 3;
+    x.hoff = x.head * D + 4 * x.c;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stage_table<D>(lds, table_q, L, h, x.head, 1);
+    stage_table<D>(lds + TS, table_k, L, h, x.head, 1);
+    stage_table<D>(lds + 2 * TS, table_v, L, h, x.head, 1);
     __syncthreads();
     const int nC = pl.counts[0];
-    float *pb = pbuf + (size_t)head * plane;
-    const int hoff = head * D + 4 * c;
-    for (int task = blockIdx.x * CA_WAVES + wave; task < nC; task += gridDim.x * CA_WAVES) {
+    float *pb = pbuf + (size_t)x.head * plane;
+    const int slots = gridDim.x * CA_WAVES, slot = blockIdx.x * CA_WAVES + wave;
+    for (int round = 0; round * slots < nC; round++) {
+        const int task = snake_task(round, slot, slots);
+        if (task >= nC) continue;
         const CellTask ct = cell_task(pl, task);
         const int nch = (ct.nk + 16 * NP - 1) / (16 * NP);
         const unsigned tile_bytes = (unsigned)ct.nq * ct.nk * 4u;
-        const rsrc_t rs_rel = make_rsrc(pl.relp + ct.pbase, tile_bytes);
+        CellBufs cb;
+        cb.rel = make_rsrc(pl.relp + ct.pbase, tile_bytes);
+        cb.key = make_rsrc(pl.cell_keys + ct.kb, (unsigned)ct.nk * 4u);
+        cb.qid = make_rsrc(pl.cell_order + ct.qs, (unsigned)ct.nq * 4u);
         const rsrc_t rs_p = make_rsrc(pb + ct.pbase, tile_bytes);
-        const rsrc_t rs_key = make_rsrc(pl.cell_keys + ct.kb, (unsigned)ct.nk * 4u);
-        const rsrc_t rs_qid = make_rsrc(pl.cell_order + ct.qs, (unsigned)ct.nq * 4u);
-        // ---- sweep 1: logits and softmax ----
-        for (int ch = 0; ch < nch; ch++) {
-            const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0), np = (nkc + 15) >> 4;
-            float4 k4[NP];
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                const int key = (int)bload_u32(rs_key, (j0 + 16 * t + p) * 4);  // (past the end: key 0, never used)
-                k4[t] = ldg4(k + (size_t)key * C + hoff);
-            }
-            // the inputs of query il+1 are requested while query il is worked on
-            int i_nx = (int)bload_u32(rs_qid, 0);
-            float4 q4_nx = ldg4(q + (size_t)i_nx * C + hoff);
-            unsigned w_nx[NP];
-#pragma unroll
-            for (int t = 0; t < NP; t++) w_nx[t] = bload_u32(rs_rel, (j0 + p) * 4 + 64 * t);
-            for (int il = 0; il < ct.nq; il++) {
-                const int i = i_nx;
-                const float4 q4 = q4_nx;
-                unsigned w[NP];
-#pragma unroll
-                for (int t = 0; t < NP; t++) w[t] = w_nx[t];
-                const int roff = (il * ct.nk + j0 + p) * 4;
-                {
-                    i_nx = (int)bload_u32(rs_qid, (il + 1) * 4);  // (past the end: query 0, never used)
-                    q4_nx = ldg4(q + (size_t)i_nx * C + hoff);
-#pragma unroll
-                    for (int t = 0; t < NP; t++)
-                        if (t < np) w_nx[t] = bload_u32(rs_rel, roff + ct.nk * 4 + 64 * t);
-                }
-                float lg[NP];
-                float mx = -INFINITY;
-#pragma unroll
-                for (int t = 0; t < NP; t++) {
-                    lg[t] = -INFINITY;
-                    if (t < np) {  // wave-uniform
-                        const RowOff ro = row_off(w[t], L, c);
-                        const float s = quad_sum(dot4(q4, k4[t]) + dot4(q4, tsum_at<0>(lds, ro)) + dot4(k4[t], tsum_at<TS>(lds, ro)));
-                        if (16 * t + p < nkc && !(w[t] >> 31)) lg[t] = s;
-                        mx = fmaxf(mx, lg[t]);
-                    }
-                }
-                mx = slots_max16(mx);
-                if (nch == 1) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int t = 0; t < NP; t++)
-                        if (t < np) {
-                            lg[t] = __expf(lg[t] - mx);  // exp(-inf) = 0: masked entries and slots past the end
-                            sum += lg[t];
-                        }
-                    const float inv = 1.0f / slots_sum16(sum);
-#pragma unroll
-                    for (int t = 0; t < NP; t++)
-                        if (t < np && c == 0 && 16 * t + p < nkc) bstore_f32(rs_p, roff + 64 * t, lg[t] * inv);
-                } else {
-                    float *st = ml + ((size_t)i * h + head) * 2;
-                    const float m_old = ch ? st[0] : -INFINITY, l_old = ch ? st[1] : 0.f;
-                    const float m_new = fmaxf(m_old, mx);
-                    float sum = 0.f;
-#pragma unroll
-                    for (int t = 0; t < NP; t++)
-                        if (t < np) {
-                            sum += __expf(lg[t] - m_new);
-                            if (c == 0 && 16 * t + p < nkc) bstore_f32(rs_p, roff + 64 * t, lg[t]);  // logits; sweep 2 makes them weights
-                        }
-                    sum = slots_sum16(sum);
-                    if (lane == 0) {
-                        st[0] = m_new;
-                        st[1] = (m_old == -INFINITY ? 0.f : l_old * __expf(m_old - m_new)) + sum;
-                    }
-                }
-            }
+        for (int ch = 0; ch < nch; ch++) {  // sweep 1: logits and softmax
+            const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0);
+            dispatch_passes<NP>((nkc + 15) >> 4, [&](auto tag) {
+                fwd_sweep_logits<decltype(tag)::value, TS>(x, ct, cb, rs_p, q, k, ml, ch, nch == 1, j0, nkc);
+            });
         }
-        // ---- sweep 2: out = sum p (v + Tv) ----
-        for (int ch = 0; ch < nch; ch++) {
-            const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0), np = (nkc + 15) >> 4;
-            float4 v4[NP];
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                const int key = (int)bload_u32(rs_key, (j0 + 16 * t + p) * 4);
-                v4[t] = ldg4(v + (size_t)key * C + hoff);
-            }
-            unsigned w_nx[NP];
-            float a_nx[NP];
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                w_nx[t] = bload_u32(rs_rel, (j0 + p) * 4 + 64 * t);
-                a_nx[t] = bload_f32(rs_p, (j0 + p) * 4 + 64 * t);
-            }
-            int i_nx = (int)bload_u32(rs_qid, 0);
-            for (int il = 0; il < ct.nq; il++) {
-                const int i = i_nx;
-                const int roff = (il * ct.nk + j0 + p) * 4;
-                unsigned w[NP];
-                float a[NP];
-#pragma unroll
-                for (int t = 0; t < NP; t++) {
-                    w[t] = w_nx[t];
-                    a[t] = a_nx[t];
-                }
-                i_nx = (int)bload_u32(rs_qid, (il + 1) * 4);
-#pragma unroll
-                for (int t = 0; t < NP; t++)
-                    if (t < np) {
-                        w_nx[t] = bload_u32(rs_rel, roff + ct.nk * 4 + 64 * t);
-                        a_nx[t] = bload_f32(rs_p, roff + ct.nk * 4 + 64 * t);
-                    }
-                if (nch > 1) {
-                    const float *st = ml + ((size_t)i * h + head) * 2;
-                    const float m = st[0], inv = 1.0f / st[1];
-#pragma unroll
-                    for (int t = 0; t < NP; t++)
-                        if (t < np) {
-                            a[t] = __expf(a[t] - m) * inv;
-                            if (c == 0 && 16 * t + p < nkc) bstore_f32(rs_p, roff + 64 * t, a[t]);
-                        }
-                }
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int t = 0; t < NP; t++)
-                    if (t < np) {
-                        const RowOff ro = row_off(w[t], L, c);
-                        const float at = 16 * t + p < nkc ? a[t] : 0.f;  // (a masked entry's weight is stored as 0)
-                        acc = fma4(at, add4(tsum_at<2 * TS>(lds, ro), v4[t]), acc);
-                    }
-                const float4 tot = slots_sum16_4(acc);
-                if (p == 0) {
-                    float *o = out + (size_t)i * C + hoff;
-                    stg4(o, ch ? add4(tot, ldg4(o)) : tot);
-                }
-            }
+#ifndef CA_SKIP_SWEEP2
+        for (int ch = 0; ch < nch; ch++) {  // sweep 2: out = sum p (v + Tv)
+            const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0);
+            dispatch_passes<NP>((nkc + 15) >> 4, [&](auto tag) {
+                fwd_sweep_values<decltype(tag)::value, TS>(x, ct, cb, rs_p, v, ml, out, ch, nch == 1, j0, nkc);
+            });
         }
+#endif
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, sweeps A and B
 // ------------------------------------------------------------------------------------------------
-// adds the key-side accumulators of one pass (lane (p, c): floats 4c..4c+3 of key slot p) to grad[key, head, :]:
+// adds the key-side accumulators of pass t (lane (p, c): floats 4c..4c+3 of the key j0 + p * NPA + t) to grad[key, head, :]:
 // through a wave-private LDS tile, so that one atomic instruction covers four whole 64-byte head rows
-__device__ __forceinline__ void flush_key_pass(float *scr, float4 acc, rsrc_t rs_key, int jbase, int nleft, float *__restrict__ grad,
-                                               int C, int head, int lane, int p, int c) {
-    *reinterpret_cast<float4 *>(scr + p * 16 + 4 * c) = acc;
+template <int NPA>
+__device__ __forceinline__ void flush_key_pass(float *scr, float4 acc, rsrc_t rs_key, int j0, int t, int nkc, float *__restrict__ grad,
+                                               const LaneCtx &x) {
+    *reinterpret_cast<float4 *>(scr + x.p * 16 + 4 * x.c) = acc;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-        const int s = (lane >> 4) + 4 * kk;
-        const int key = (int)bload_u32(rs_key, (jbase + s) * 4);
-        if (s < nleft) unsafeAtomicAdd(grad + (size_t)key * C + head * 16 + (lane & 15), scr[s * 16 + (lane & 15)]);
+        const int s = (x.lane >> 4) + 4 * kk;
+        const int jl = s * NPA + t;
+        const int key = (int)bload_u32(rs_key, (j0 + jl) * 4);
+        if (jl < nkc) unsafeAtomicAdd(grad + (size_t)key * x.C + x.head * 16 + (x.lane & 15), scr[s * 16 + (x.lane & 15)]);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
 }
 
+// sweep A: grad_attn = <go, v + Tv>, gs = p (grad_attn - <go, out>) stored, dV += p go
+template <int NPA, int TS>
+__device__ __forceinline__ void bwd_sweep_values(const LaneCtx &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p, rsrc_t rs_g,
+                                                 float *scr, const float *__restrict__ go, const float *__restrict__ out,
+                                                 const float *__restrict__ v, float *__restrict__ grad_v, int j0, int nkc) {
+    const int p = x.p, c = x.c;
+    const int nvalid = min(max(nkc - p * NPA, 0), NPA);
+    float4 v4[NPA], dv4[NPA];
+    load_key_rows<NPA>(x, cb, v, j0, v4);
+#pragma unroll
+    for (int t = 0; t < NPA; t++) dv4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned w_nx[NPA];
+    float a_nx[NPA];
+    bload_words<NPA>(cb.rel, (j0 + p * NPA) * 4, w_nx);
+    bload_floats<NPA>(rs_p, (j0 + p * NPA) * 4, a_nx);
+    int ids = (int)bload_u32(cb.qid, x.lane * 4);
+    int i_nx = __builtin_amdgcn_readlane(ids, 0);
+    float4 go_nx = ldg4(go + (size_t)i_nx * x.C + x.hoff), o_nx = ldg4(out + (size_t)i_nx * x.C + x.hoff);
+    for (int il = 0; il < ct.nq; il++) {
+        const int roff = (il * ct.nk + j0 + p * NPA) * 4;
+        const float4 go4 = go_nx, o4 = o_nx;
+        unsigned w[NPA];
+        float a[NPA];
+#pragma unroll
+        for (int t = 0; t < NPA; t++) {
+            w[t] = w_nx[t];
+            a[t] = t < nvalid ? a_nx[t] : 0.f;
+        }
+        if (((il + 1) & 63) == 0) ids = (int)bload_u32(cb.qid, (il + 1 + x.lane) * 4);
+        i_nx = __builtin_amdgcn_readlane(ids, (il + 1) & 63);
+        go_nx = ldg4(go + (size_t)i_nx * x.C + x.hoff);
+        o_nx = ldg4(out + (size_t)i_nx * x.C + x.hoff);
+        bload_words<NPA>(cb.rel, roff + ct.nk * 4, w_nx);
+        bload_floats<NPA>(rs_p, roff + ct.nk * 4, a_nx);
+        const float delta = quad_sum(pdot4(go4, o4));  // = sum over the row of p * grad_attn
+        float gs[NPA];
+        Rows3 rv = rows_at<2 * TS>(x.lds, row_off(w[0], x.L, c));
+#pragma unroll
+        for (int t = 0; t < NPA; t++) {
+            Rows3 rv1 = rv;
+            if (t + 1 < NPA) rv1 = rows_at<2 * TS>(x.lds, row_off(w[t + 1], x.L, c));
+            const float ga = quad_sum(pdot4(go4, padd4(rsum(rv), v4[t])));
+            gs[t] = a[t] * (ga - delta);
+            dv4[t] = pfma4(a[t], go4, dv4[t]);
+            rv = rv1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c == 0) bstore_floats<NPA>(rs_g, roff, gs, nvalid);
+    }
+#pragma unroll
+    for (int t = 0; t < NPA; t++) flush_key_pass<NPA>(scr, dv4[t], cb.key, j0, t, nkc, grad_v, x);
+}
+
+// sweep B: dQ = sum gs (k + Tq), dK += gs (q + Tk)
+template <int NPA, int TS>
+__device__ __forceinline__ void bwd_sweep_keys(const LaneCtx &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_g, float *scr,
+                                               const float *__restrict__ q, const float *__restrict__ k, float *__restrict__ grad_q,
+                                               float *__restrict__ grad_k, int ch, int j0, int nkc) {
+    const int p = x.p, c = x.c;
+    const int nvalid = min(max(nkc - p * NPA, 0), NPA);
+    float4 k4[NPA], dk4[NPA];
+    load_key_rows<NPA>(x, cb, k, j0, k4);
+#pragma unroll
+    for (int t = 0; t < NPA; t++) dk4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned w_nx[NPA];
+    float g_nx[NPA];
+    bload_words<NPA>(cb.rel, (j0 + p * NPA) * 4, w_nx);
+    bload_floats<NPA>(rs_g, (j0 + p * NPA) * 4, g_nx);
+    int ids = (int)bload_u32(cb.qid, x.lane * 4);
+    int i_nx = __builtin_amdgcn_readlane(ids, 0);
+    float4 q_nx = ldg4(q + (size_t)i_nx * x.C + x.hoff);
+    for (int il = 0; il < ct.nq; il++) {
+        const int i = i_nx;
+        const int roff = (il * ct.nk + j0 + p * NPA) * 4;
+        const float4 q4 = q_nx;
+        unsigned w[NPA];
+        float g[NPA];
+#pragma unroll
+        for (int t = 0; t < NPA; t++) {
+            w[t] = w_nx[t];
+            g[t] = t < nvalid ? g_nx[t] : 0.f;
+        }
+        if (((il + 1) & 63) == 0) ids = (int)bload_u32(cb.qid, (il + 1 + x.lane) * 4);
+        i_nx = __builtin_amdgcn_readlane(ids, (il + 1) & 63);
+        q_nx = ldg4(q + (size_t)i_nx * x.C + x.hoff);
+        bload_words<NPA>(cb.rel, roff + ct.nk * 4, w_nx);
+        bload_floats<NPA>(rs_g, roff + ct.nk * 4, g_nx);
+        float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+        RowOff ro = row_off(w[0], x.L, c);
+        Rows3 rq = rows_at<0>(x.lds, ro), rk = rows_at<TS>(x.lds, ro);
+#pragma unroll
+        for (int t = 0; t < NPA; t++) {
+            Rows3 rq1 = rq, rk1 = rk;
+            if (t + 1 < NPA) {
+                ro = row_off(w[t + 1], x.L, c);
+                rq1 = rows_at<0>(x.lds, ro);
+                rk1 = rows_at<TS>(x.lds, ro);
+            }
+            dq = pfma4(g[t], padd4(rsum(rq), k4[t]), dq);
+            dk4[t] = pfma4(g[t], padd4(rsum(rk), q4), dk4[t]);
+            rq = rq1;
+            rk = rk1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 tot = slots_sum16_4(dq);
+        if (p == 0) {
+            float *o = grad_q + (size_t)i * x.C + x.hoff;
+            stg4(o, ch ? add4(tot, ldg4(o)) : tot);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NPA; t++) flush_key_pass<NPA>(scr, dk4[t], cb.key, j0, t, nkc, grad_k, x);
+}
+
 template <int NP, int LCAP>
-__global__ __launch_bounds__(CA_WAVES * 64) void cell_bwd_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ go,
+__global__ __launch_bounds__(CA_WAVES_BWD * 64) void cell_bwd_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ go,
                                                                  const float *__restrict__ q, const float *__restrict__ k,
                                                                  const float *__restrict__ v, const float *__restrict__ out,
                                                                  const float *__restrict__ table_q, const float *__restrict__ table_k,
@@ -305,144 +576,65 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_bwd_kernel(pointops2_cell_
                                                                  float *__restrict__ grad_k, float *__restrict__ grad_v) {
     constexpr int D = 16, TS = TabGeo<LCAP>::TS;
     extern __shared__ float lds[];
-    const int head = blockIdx.y, C = h * D;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, p = lane >> 2, c = lane & 3;
+    LaneCtx x;
+    x.lds = lds;
+    x.L = L;
+    x.h = h;
+    x.head = blockIdx.y;
+    x.C = h * D;
+    x.lane = threadIdx.x & 63;
+    x.p = x.lane >> 2;
+    x.c = x.lane & 3;
+    x.hoff = x.head * D + 4 * x.c;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *scr = lds + 3 * TS + wave * 256;
-    stage_table<D>(lds, table_q, L, h, head, 1);
-    stage_table<D>(lds + TS, table_k, L, h, head, 1);
-    stage_table<D>(lds + 2 * TS, table_v, L, h, head, 1);
+    stage_table<D>(lds, table_q, L, h, x.head, 1);
+    stage_table<D>(lds + TS, table_k, L, h, x.head, 1);
+    stage_table<D>(lds + 2 * TS, table_v, L, h, x.head, 1);
     __syncthreads();
     const int nC = pl.counts[0];
-    const float *pb = pbuf + (size_t)head * plane;
-    float *gb = gsbuf + (size_t)head * plane;
-    const int hoff = head * D + 4 * c;
-    for (int task = blockIdx.x * CA_WAVES + wave; task < nC; task += gridDim.x * CA_WAVES) {
+    const float *pb = pbuf + (size_t)x.head * plane;
+    float *gb = gsbuf + (size_t)x.head * plane;
+    const int slots = gridDim.x * CA_WAVES_BWD, slot = blockIdx.x * CA_WAVES_BWD + wave;
+    for (int round = 0; round * slots < nC; round++) {
+        const int task = snake_task(round, slot, slots);
+        if (task >= nC) continue;
         const CellTask ct = cell_task(pl, task);
         const int nch = (ct.nk + 16 * NP - 1) / (16 * NP);
         const unsigned tile_bytes = (unsigned)ct.nq * ct.nk * 4u;
-        const rsrc_t rs_rel = make_rsrc(pl.relp + ct.pbase, tile_bytes);
+        CellBufs cb;
+        cb.rel = make_rsrc(pl.relp + ct.pbase, tile_bytes);
+        cb.key = make_rsrc(pl.cell_keys + ct.kb, (unsigned)ct.nk * 4u);
+        cb.qid = make_rsrc(pl.cell_order + ct.qs, (unsigned)ct.nq * 4u);
         const rsrc_t rs_p = make_rsrc(pb + ct.pbase, tile_bytes);
         const rsrc_t rs_g = make_rsrc(gb + ct.pbase, tile_bytes);
-        const rsrc_t rs_key = make_rsrc(pl.cell_keys + ct.kb, (unsigned)ct.nk * 4u);
-        const rsrc_t rs_qid = make_rsrc(pl.cell_order + ct.qs, (unsigned)ct.nq * 4u);
-        // ---- sweep A: grad_attn = <go, v + Tv>, gs = p (grad_attn - <go, out>), dV += p go ----
         for (int ch = 0; ch < nch; ch++) {
-            const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0), np = (nkc + 15) >> 4;
-            float4 v4[NP], dv4[NP];
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                const int key = (int)bload_u32(rs_key, (j0 + 16 * t + p) * 4);
-                v4[t] = ldg4(v + (size_t)key * C + hoff);
-                dv4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            unsigned w_nx[NP];
-            float a_nx[NP];
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                w_nx[t] = bload_u32(rs_rel, (j0 + p) * 4 + 64 * t);
-                a_nx[t] = bload_f32(rs_p, (j0 + p) * 4 + 64 * t);
-            }
-            int i_nx = (int)bload_u32(rs_qid, 0);
-            float4 go_nx = ldg4(go + (size_t)i_nx * C + hoff), o_nx = ldg4(out + (size_t)i_nx * C + hoff);
-            for (int il = 0; il < ct.nq; il++) {
-                const int roff = (il * ct.nk + j0 + p) * 4;
-                const float4 go4 = go_nx, o4 = o_nx;
-                unsigned w[NP];
-                float a[NP];
-#pragma unroll
-                for (int t = 0; t < NP; t++) {
-                    w[t] = w_nx[t];
-                    a[t] = a_nx[t];
-                }
-                i_nx = (int)bload_u32(rs_qid, (il + 1) * 4);
-                go_nx = ldg4(go + (size_t)i_nx * C + hoff);
-                o_nx = ldg4(out + (size_t)i_nx * C + hoff);
-#pragma unroll
-                for (int t = 0; t < NP; t++)
-                    if (t < np) {
-                        w_nx[t] = bload_u32(rs_rel, roff + ct.nk * 4 + 64 * t);
-                        a_nx[t] = bload_f32(rs_p, roff + ct.nk * 4 + 64 * t);
-                    }
-                const float delta = quad_sum(dot4(go4, o4));  // = sum over the row of p * grad_attn
-#pragma unroll
-                for (int t = 0; t < NP; t++)
-                    if (t < np) {
-                        const RowOff ro = row_off(w[t], L, c);
-                        const float at = 16 * t + p < nkc ? a[t] : 0.f;
-                        const float ga = quad_sum(dot4(go4, add4(tsum_at<2 * TS>(lds, ro), v4[t])));
-                        if (c == 0 && 16 * t + p < nkc) bstore_f32(rs_g, roff + 64 * t, at * (ga - delta));
-                        dv4[t] = fma4(at, go4, dv4[t]);
-                    }
-            }
-#pragma unroll
-            for (int t = 0; t < NP; t++)
-                if (t < np) flush_key_pass(scr, dv4[t], rs_key, j0 + 16 * t, nkc - 16 * t, grad_v, C, head, lane, p, c);
+            const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0);
+            dispatch_passes<NP>((nkc + 15) >> 4, [&](auto tag) {
+                bwd_sweep_values<decltype(tag)::value, TS>(x, ct, cb, rs_p, rs_g, scr, go, out, v, grad_v, j0, nkc);
+            });
         }
-        // ---- sweep B: dQ = sum gs (k + Tq), dK += gs (q + Tk) ----
         for (int ch = 0; ch < nch; ch++) {
-            const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0), np = (nkc + 15) >> 4;
-            float4 k4[NP], dk4[NP];
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                const int key = (int)bload_u32(rs_key, (j0 + 16 * t + p) * 4);
-                k4[t] = ldg4(k + (size_t)key * C + hoff);
-                dk4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            unsigned w_nx[NP];
-            float g_nx[NP];
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                w_nx[t] = bload_u32(rs_rel, (j0 + p) * 4 + 64 * t);
-                g_nx[t] = bload_f32(rs_g, (j0 + p) * 4 + 64 * t);
-            }
-            int i_nx = (int)bload_u32(rs_qid, 0);
-            float4 q_nx = ldg4(q + (size_t)i_nx * C + hoff);
-            for (int il = 0; il < ct.nq; il++) {
-                const int i = i_nx;
-                const int roff = (il * ct.nk + j0 + p) * 4;
-                const float4 q4 = q_nx;
-                unsigned w[NP];
-                float g[NP];
-#pragma unroll
-                for (int t = 0; t < NP; t++) {
-                    w[t] = w_nx[t];
-                    g[t] = g_nx[t];
-                }
-                i_nx = (int)bload_u32(rs_qid, (il + 1) * 4);
-                q_nx = ldg4(q + (size_t)i_nx * C + hoff);
-#pragma unroll
-                for (int t = 0; t < NP; t++)
-                    if (t < np) {
-                        w_nx[t] = bload_u32(rs_rel, roff + ct.nk * 4 + 64 * t);
-                        g_nx[t] = bload_f32(rs_g, roff + ct.nk * 4 + 64 * t);
-                    }
-                float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int t = 0; t < NP; t++)
-                    if (t < np) {
-                        const RowOff ro = row_off(w[t], L, c);
-                        const float gt = 16 * t + p < nkc ? g[t] : 0.f;
-                        dq = fma4(gt, add4(tsum_at<0>(lds, ro), k4[t]), dq);
-                        dk4[t] = fma4(gt, add4(tsum_at<TS>(lds, ro), q4), dk4[t]);
-                    }
-                const float4 tot = slots_sum16_4(dq);
-                if (p == 0) {
-                    float *o = grad_q + (size_t)i * C + hoff;
-                    stg4(o, ch ? add4(tot, ldg4(o)) : tot);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < NP; t++)
-                if (t < np) flush_key_pass(scr, dk4[t], rs_key, j0 + 16 * t, nkc - 16 * t, grad_k, C, head, lane, p, c);
+            const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0);
+            dispatch_passes<NP>((nkc + 15) >> 4, [&](auto tag) {
+                bwd_sweep_keys<decltype(tag)::value, TS>(x, ct, cb, rs_g, scr, q, k, grad_q, grad_k, ch, j0, nkc);
+            });
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// table gradients on cell rows (the scheme of rpe_bwd_mfma.hip's table_grad_kernel, see its header):
-//   BYKEY = false: rows = sorted query positions; a row is the query's contiguous row of its cell's tile; X = q or grad_out
-//   BYKEY = true:  rows = key slots; a row is the key's column of the tile (stride n_k); X = k
-// grad_table[r, head, i, ax] += sum over rows, over the row's entries with rel[ax] == r, of w * X[row point, head, i]
+// table gradients on cell tiles.  grad_table[r, head, i, ax] += sum over tile entries with rel[ax] == r of w * X[row point, head, i]
+//   BYKEY = false: a row = a query (its row of the tile), X = q (w = logit gradients) or grad_out (w = softmax weights)
+//   BYKEY = true:  a row = a key   (its column of the tile), X = k (w = logit gradients)
+// The sum is factored per row as in rpe_bwd_mfma.hip: a 3 x L histogram of the row's weights by rel index (32-bit fixed
+// point: LDS integer atomics run at LDS write speed, float ones at ~1 lane per 3 cycles), times the row's X vector - an
+// outer product, taken on the matrix cores four rows at a time: D[bin, i] += A[bin, row] * B[row, i] is one
+// v_mfma_f32_16x16x4_f32 per 16-bin tile and axis.  Here a wave works alone: it takes FOUR ADJACENT ROWS of a cell at
+// once (lane (p, c): entry p of a pass, row c of the four - for keys the four columns are 16 contiguous bytes per query),
+// keeps the whole table slice of its head in accumulators (TA x 3 tiles) and meets the other waves of its workgroup only
+// at the end, when the accumulators are summed through LDS and leave as contiguous atomics.  No row claims, no
+// barriers, no descriptor chains in the loop: a cell's rows share one set of scalars.
 // ------------------------------------------------------------------------------------------------
 struct CFixScale {
     float mul, inv;
@@ -462,179 +654,189 @@ __device__ __forceinline__ CFixScale c_row_scale(unsigned maxbits, int n) {
     return sc;
 }
 
-constexpr int CT_WAVES = 12;  // rows per group = K of the outer-product step (3 x 4)
-constexpr int CT_MAXP = 8;    // passes of 16 entries a row segment is walked from registers
+constexpr int CT_WAVES = 12;
 
 template <int TA>
 struct CellTableGeo {
     static constexpr int LP = TA * 16;       // padded bins per axis
-    static constexpr int ROW = 3 * LP + 16;  // ints per histogram row (+16: the four k-rows of one ds_read on different banks)
-    static constexpr size_t walk_bytes() { return (size_t)CT_WAVES * (ROW + 16) * 4; }
-    static constexpr size_t flush_bytes() { return (size_t)CT_WAVES * 16 * 48 * 4; }
-    static constexpr size_t lds_bytes() { return walk_bytes() > flush_bytes() ? walk_bytes() : flush_bytes(); }
+    static constexpr int ROW = 3 * LP + 16;  // ints per histogram row (+16: the four rows of one read on different banks)
+    static constexpr size_t walk_bytes() { return (size_t)CT_WAVES * 4 * ROW * 4; }
+    static constexpr size_t sum_bytes() { return (size_t)LP * 48 * 4; }
+    static constexpr size_t lds_bytes() { return walk_bytes() > sum_bytes() ? walk_bytes() : sum_bytes(); }
 };
 
 template <int TA, bool BYKEY>
-__global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops2_cell_plan pl, int nrows_fixed, int h, int L,
-                                                                        const float *__restrict__ wbuf, size_t plane,
-                                                                        const float *__restrict__ X, float *__restrict__ grad_table) {
-    constexpr int D = 16, NW = CT_WAVES;
+__global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ wbuf,
+                                                                        size_t plane, const float *__restrict__ X,
+                                                                        float *__restrict__ grad_table) {
+    constexpr int D = 16;
+    constexpr int MAXP = BYKEY ? 4 : 8;  // passes of 16 entries per row a segment holds in registers (a key's column is short)
     using G = CellTableGeo<TA>;
     extern __shared__ float lds[];
-    int *hist = reinterpret_cast<int *>(lds);  // [NW][ROW]
-    float *xs = lds + NW * G::ROW;             // [NW][16]: X rows of the group, scaled by 2^-S
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int C = h * D;
-    const int p = lane >> 2, c = lane & 3;
-    const int head = blockIdx.y;
-    const int kq = lane >> 4, col = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int C = h * D, head = blockIdx.y;
+    const int p = lane >> 2, c = lane & 3;     // entry of a pass, row of the four
+    const int kq = lane >> 4, col = lane & 15;  // MFMA operand coordinates: row of the four, bin / feature
+    int *hist = reinterpret_cast<int *>(lds) + wave * 4 * G::ROW;  // [4][ROW], private to the wave
     const float *wb = wbuf + (size_t)head * plane;
-    const int N = nrows_fixed;  // rows: key slots | queries
 
-    f32x4c acc[3];
+    f32x4c acc[TA][3];
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++) acc[ax] = f32x4c{0.f, 0.f, 0.f, 0.f};
-    for (int x = threadIdx.x; x < NW * G::ROW; x += NW * 64) hist[x] = 0;
-    __shared__ int next_row;
-    const int per = (N + gridDim.x - 1) / gridDim.x;
-    const int rb = min(N, (int)blockIdx.x * per), re = min(N, rb + per);
-    if (threadIdx.x == 0) next_row = rb;
-    __syncthreads();
-    int *myh = hist + wave * G::ROW;
-    auto claim = [&]() -> int {
-        int r = 0;
-        if (lane == 0) r = atomicAdd(&next_row, 1);
-        r = __builtin_amdgcn_readfirstlane(r);
-        return r < re ? r : -1;
-    };
-    // a row = (first entry, entries, stride between entries, point whose X row it multiplies)
-    struct Row {
-        size_t start;
-        int n, stride, point;
-    };
-    auto describe = [&](int r) -> Row {
-        Row d;
+    for (int bt = 0; bt < TA; bt++)
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) acc[bt][ax] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    for (int x = lane; x < 4 * G::ROW; x += 64) hist[x] = 0;
+
+    // rows = queries: a task is a cell (piece), largest first; rows = keys: a task is a parent (all pieces of an uncut cell:
+    // one [sum n_q, n_k] tile), so that a key's column is as long as the cut allows
+    const int nC = BYKEY ? pl.counts[4] : pl.counts[0];
+    const int slots = gridDim.x * CT_WAVES, slot = blockIdx.x * CT_WAVES + wave;
+    for (int round = 0; round * slots < nC; round++) {
+        const int task = snake_task(round, slot, slots);
+        if (task >= nC) continue;
+        CellTask ct;
         if (BYKEY) {
-            const int cell = pl.kcell[r];
-            const int kb = pl.cell_kbase[cell];
-            d.stride = pl.cell_kbase[cell + 1] - kb;
-            d.start = (size_t)pl.cell_pbase[cell] + (r - kb);
-            d.n = pl.cell_qstart[cell + 1] - pl.cell_qstart[cell];
-            d.point = pl.cell_keys[r];
+            const int c0 = __builtin_amdgcn_readfirstlane(pl.parent_first[task]), c1 = __builtin_amdgcn_readfirstlane(pl.parent_first[task + 1]);
+            ct.qs = __builtin_amdgcn_readfirstlane(pl.cell_qstart[c0]);
+            ct.nq = __builtin_amdgcn_readfirstlane(pl.cell_qstart[c1]) - ct.qs;
+            ct.kb = __builtin_amdgcn_readfirstlane(pl.cell_kbase[c0]);
+            ct.nk = __builtin_amdgcn_readfirstlane(pl.cell_kbase[c0 + 1]) - ct.kb;
+            ct.pbase = __builtin_amdgcn_readfirstlane(pl.cell_pbase[c0]);
         } else {
-            const int cell = pl.qcell[r];
-            const int nk = pl.cell_kbase[cell + 1] - pl.cell_kbase[cell];
-            d.stride = 1;
-            d.start = (size_t)pl.cell_pbase[cell] + (size_t)(r - pl.cell_qstart[cell]) * nk;
-            d.n = nk;
-            d.point = pl.cell_order[r];
+            ct = cell_task(pl, task);
         }
-        return d;
-    };
-    int row = -1, cur = 0;
-    Row rd{0, 0, 1, 0}, nrd{0, 0, 1, 0};
-    int nrow = claim();
-    if (nrow >= 0) nrd = describe(nrow);
-    for (;;) {
-        if (cur >= rd.n || row < 0) {  // this wave's row is finished: take the claimed one (none left: row = -1 from here on)
-            row = nrow;
-            rd = nrd;
-            cur = 0;
-            nrow = -1;
-            if (row < 0) rd.n = 0;
-        }
-        const bool last_segment = row >= 0 && rd.n - cur <= 16 * CT_MAXP;
-        if (row >= 0) {
-            const int s = cur, e = min(rd.n, cur + 16 * CT_MAXP);
-            cur = e;
-            const int np = (e - s + 15) >> 4;
-            unsigned rreg[CT_MAXP];
-            float wreg[CT_MAXP];
-#pragma unroll
-            for (int i = 0; i < CT_MAXP; i++) { rreg[i] = 0; wreg[i] = 0.f; }
-            const float4 x4 = ldg4(X + (size_t)rd.point * C + head * D + 4 * c);
-            if (e > s) {
-#pragma unroll
-                for (int i = 0; i < CT_MAXP; i++) {
-                    const size_t pos = rd.start + (size_t)min(s + i * 16 + p, e - 1) * rd.stride;
-                    rreg[i] = pl.relp[pos];
-                    wreg[i] = wb[pos];
-                }
-            }
-            if (last_segment) {  // wave-uniform; behind this segment's loads so that the claim's round trips overlap them
-                nrow = claim();
-                if (nrow >= 0) nrd = describe(nrow);
-            }
+        const unsigned tile_bytes = (unsigned)ct.nq * ct.nk * 4u;
+        const rsrc_t rs_rel = make_rsrc(pl.relp + ct.pbase, tile_bytes);
+        const rsrc_t rs_w = make_rsrc(wb + ct.pbase, tile_bytes);
+        const rsrc_t rs_row = BYKEY ? make_rsrc(pl.cell_keys + ct.kb, (unsigned)ct.nk * 4u) : make_rsrc(pl.cell_order + ct.qs, (unsigned)ct.nq * 4u);
+        const int nrows = BYKEY ? ct.nk : ct.nq, nent = BYKEY ? ct.nq : ct.nk;
+        // entry e of row r0 + c: rows = keys: tile[e][r0 + c];  rows = queries: tile[r0 + c][e]
+        auto entry_off = [&](int r0, int ent) -> int { return (BYKEY ? ent * ct.nk + r0 + c : (r0 + c) * ct.nk + ent) * 4; };
+        // one segment (<= 16 * MAXP entries per row) of the four rows r0..r0+3: histograms, then the outer products
+        auto consume = [&](int r0, int e0, float xv, unsigned (&wr)[MAXP], float (&wt)[MAXP]) {
+            const int ne = min(nent - e0, 16 * MAXP);
+            const bool row_ok = r0 + c < nrows;
             unsigned mxb = 0u;
 #pragma unroll
-            for (int i = 0; i < CT_MAXP; i++) {
-                const bool live = s + i * 16 + p < e && !(rreg[i] >> 31);
-                wreg[i] = live ? wreg[i] : 0.f;
-                mxb = max(mxb, __float_as_uint(fabsf(wreg[i])));
+            for (int t = 0; t < MAXP; t++) {
+                const bool live = row_ok && e0 + 16 * t + p < nent && !(wr[t] >> 31);
+                wt[t] = live ? wt[t] : 0.f;
+                mxb = max(mxb, __float_as_uint(fabsf(wt[t])));
             }
-            const CFixScale sc = c_row_scale(wave_max_u32(mxb), e - s);
-            if (lane < 4)
-                *reinterpret_cast<float4 *>(&xs[wave * 16 + 4 * c]) = make_float4(x4.x * sc.inv, x4.y * sc.inv, x4.z * sc.inv, x4.w * sc.inv);
+            const CFixScale sc = c_row_scale(wave_max_u32(mxb), ne);
+            int *myh = hist + c * G::ROW;
 #pragma unroll
-            for (int i = 0; i < CT_MAXP; i++) {
-                if (i < np) {  // wave-uniform
-                    const int r = (rreg[i] >> (8 * min(c, 2))) & 255;
-                    if (wreg[i] != 0.f && c < 3) atomicAdd(&myh[c * G::LP + r], __float2int_rn(wreg[i] * sc.mul));
+            for (int t = 0; t < MAXP; t++) {
+                if (16 * t < ne && wt[t] != 0.f) {
+                    const int v = __float2int_rn(wt[t] * sc.mul);
+                    atomicAdd(&myh[wr[t] & 255u], v);
+                    atomicAdd(&myh[G::LP + ((wr[t] >> 8) & 255u)], v);
+                    atomicAdd(&myh[2 * G::LP + ((wr[t] >> 16) & 255u)], v);
                 }
             }
-        } else if (lane < 4) {
-            *reinterpret_cast<float4 *>(&xs[wave * 16 + 4 * c]) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const int more = __syncthreads_or(row >= 0);
-        if (!more) break;
-        if (wave < TA) {  // wave bt owns the three axis tiles of bin tile bt
-            const int bt = wave;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            const float b = xv * sc.inv;
 #pragma unroll
-            for (int ks = 0; ks < NW / 4; ks++) {
-                const int rk = ks * 4 + kq;
-                const float b = xs[rk * 16 + col];
+            for (int bt = 0; bt < TA; bt++)
 #pragma unroll
                 for (int ax = 0; ax < 3; ax++) {
-                    int *hp = &hist[rk * G::ROW + ax * G::LP + bt * 16 + col];
-                    const float a = (float)*hp;
-                    *hp = 0;
-                    acc[ax] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[ax], 0, 0, 0);
+                    // read the bin and clear it for the next segment in one LDS operation
+                    const float a = (float)__hip_atomic_exchange(&hist[kq * G::ROW + ax * G::LP + bt * 16 + col], 0, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                    acc[bt][ax] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[bt][ax], 0, 0, 0);
                 }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        };
+        // Software pipeline over the cell's row quads: while quad q is consumed, the first segment and the X rows of quad
+        // q+1 and the row ids of quad q+2 are in flight (an id, the X row it addresses and the tile entries would otherwise
+        // be two dependent memory round trips per quad).  Reads past the end of a buffer return 0 and are never used.
+        unsigned wr_n[MAXP];
+        float wt_n[MAXP];
+#pragma unroll
+        for (int t = 0; t < MAXP; t++) {
+            wr_n[t] = 0x80000000u;
+            wt_n[t] = 0.f;
+            if (16 * t < nent) {  // wave-uniform
+                wr_n[t] = bload_u32(rs_rel, entry_off(0, 16 * t + p));
+                wt_n[t] = bload_f32(rs_w, entry_off(0, 16 * t + p));
             }
+        }
+        int pt_n = (int)bload_u32(rs_row, kq * 4);
+        float xv_n = X[(size_t)pt_n * C + head * D + col];  // B operand: X[point of row r0 + kq, head, col]
+        pt_n = (int)bload_u32(rs_row, (4 + kq) * 4);
+        for (int r0 = 0; r0 < nrows; r0 += 4) {
+            unsigned wr[MAXP];
+            float wt[MAXP];
+#pragma unroll
+            for (int t = 0; t < MAXP; t++) {
+                wr[t] = wr_n[t];
+                wt[t] = wt_n[t];
+            }
+            const float xv = r0 + kq < nrows ? xv_n : 0.f;
+            xv_n = X[(size_t)pt_n * C + head * D + col];
+            pt_n = (int)bload_u32(rs_row, (r0 + 8 + kq) * 4);
+#pragma unroll
+            for (int t = 0; t < MAXP; t++)
+                if (16 * t < nent) {
+                    wr_n[t] = bload_u32(rs_rel, entry_off(r0 + 4, 16 * t + p));
+                    wt_n[t] = bload_f32(rs_w, entry_off(r0 + 4, 16 * t + p));
+                }
+            consume(r0, 0, xv, wr, wt);
+            for (int e0 = 16 * MAXP; e0 < nent; e0 += 16 * MAXP) {  // rows longer than one segment (rare)
+#pragma unroll
+                for (int t = 0; t < MAXP; t++) {
+                    wr[t] = bload_u32(rs_rel, entry_off(r0, e0 + 16 * t + p));
+                    wt[t] = bload_f32(rs_w, entry_off(r0, e0 + 16 * t + p));
+                }
+                consume(r0, e0, xv, wr, wt);
+            }
+        }
+    }
+    // Sum over the workgroup's waves through one LDS image in table order ([bin][16][3]: the 48 floats of a (bin, head) are
+    // contiguous in the [L, h, 16, 3] table), then contiguous atomics.  C/D layout of 16x16x4: lane holds
+    // D[row = (lane >> 4) * 4 + reg][col = lane & 15]  (row = bin, col = feature).
+    __syncthreads();  // every wave is done with its histograms
+    float *sum = lds;
+    for (int w = 0; w < CT_WAVES; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int bt = 0; bt < TA; bt++)
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        float *d = &sum[((bt * 16 + kq * 4 + reg) * 16 + col) * 3 + ax];
+                        *d = w ? *d + acc[bt][ax][reg] : acc[bt][ax][reg];
+                    }
         }
         __syncthreads();
     }
-    // flush: the wave's (bin tile, 3 axes) goes through LDS in table order ([L, h, 16, 3]: the 48 floats of one (bin, head)
-    // are contiguous) and leaves as 12 instructions of 64 consecutive floats
-    __syncthreads();
-    if (wave < TA) {
-        float *stage = lds + wave * (16 * 48);
-        const int bt = wave;
-#pragma unroll
-        for (int ax = 0; ax < 3; ax++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) stage[((kq * 4 + reg) * 16 + col) * 3 + ax] = acc[ax][reg];
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int x = lane; x < 16 * 48; x += 64) {
-            const int bin = bt * 16 + x / 48;
-            const float val = stage[x];
-            if (bin < L && val != 0.f) unsafeAtomicAdd(grad_table + ((size_t)bin * h + head) * 48 + x % 48, val);
-        }
+    for (int x = threadIdx.x; x < L * 48; x += CT_WAVES * 64) {
+        const float val = sum[x];
+        if (val != 0.f) unsafeAtomicAdd(grad_table + ((size_t)(x / 48) * h + head) * 48 + x % 48, val);
     }
 }
 
-static int cell_grid_x(int N, int h) {
-    // persistent grid: two workgroups per CU over all heads, never more waves than a generous bound on the cells
+static int device_cus() {
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = kNumCU;
         return n;
     }();
-    const int cap = max(1, 2 * cus / max(h, 1));
-    return max(1, min(cap, div_up(N, CA_WAVES)));
+    return cus;
+}
+// persistent grid of the cell walkers: exactly the workgroups the chip holds at once (tasks are dealt to resident waves;
+// a workgroup that had to wait for a CU would start its share late), over all heads; never more waves than tasks
+template <typename K>
+static int cell_grid_x(K kernel, size_t lds, int tasks, int h, int waves = CA_WAVES) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), waves * 64, lds) != hipSuccess || per_cu <= 0)
+        per_cu = 1;
+    const int cap = max(1, per_cu * device_cus() / max(h, 1));
+    return max(1, min(cap, div_up(tasks, waves)));
 }
 
 }  // namespace p2
@@ -649,16 +851,18 @@ void cell_attention_forward_launcher(const pointops2_cell_plan *plan, int h, int
     if (plan == nullptr || plan->n_points <= 0) return;
     if (hdim != 16) { set_error("cell_attention: d != 16"); return; }
     if (L < 1) { set_error("cell_attention: no table rows"); return; }
-    const dim3 grid(cell_grid_x(plan->n_points, h), h), block(CA_WAVES * 64);
+    const dim3 block(CA_WAVES * 64);
     const size_t plane = (size_t)plan->n_pairs;
     if (L <= 80) {
         const size_t lds = TabGeo<80>::bytes();
         allow_big_lds(cell_fwd_kernel<CA_NP, 80>, lds);
+        const dim3 grid(cell_grid_x(cell_fwd_kernel<CA_NP, 80>, lds, plan->n_cells, h), h);
         hipLaunchKernelGGL((cell_fwd_kernel<CA_NP, 80>), grid, block, lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out, ml,
                            pbuf, plane);
     } else if (L <= 160) {
         const size_t lds = TabGeo<160>::bytes();
         allow_big_lds(cell_fwd_kernel<CA_NP, 160>, lds);
+        const dim3 grid(cell_grid_x(cell_fwd_kernel<CA_NP, 160>, lds, plan->n_cells, h), h);
         hipLaunchKernelGGL((cell_fwd_kernel<CA_NP, 160>), grid, block, lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out, ml,
                            pbuf, plane);
     } else {
@@ -676,31 +880,26 @@ void cell_attention_backward_launcher(const pointops2_cell_plan *plan, int h, in
     if (hdim != 16) { set_error("cell_attention: d != 16"); return; }
     if (L < 1 || L > 80) { set_error("cell_attention backward: table rows L must be in 1..80"); return; }
     hipStream_t st = state().stream;
-    const size_t lds = TabGeo<80>::bytes() + (size_t)CA_WAVES * 256 * sizeof(float);
-    allow_big_lds(cell_bwd_kernel<CA_NP, 80>, lds);
+    const size_t lds = TabGeo<80>::bytes() + (size_t)CA_WAVES_BWD * 256 * sizeof(float);
+    allow_big_lds(cell_bwd_kernel<CA_NP_BWD, 80>, lds);
     const int N = plan->n_points;
     const size_t plane = (size_t)plan->n_pairs;
-    hipLaunchKernelGGL((cell_bwd_kernel<CA_NP, 80>), dim3(cell_grid_x(N, h), h), dim3(CA_WAVES * 64), lds, st, *plan, h, L, grad_out, q, k, v, out,
-                       table_q, table_k, table_v, pbuf, gsbuf, plane, grad_q, grad_k, grad_v);
+    hipLaunchKernelGGL((cell_bwd_kernel<CA_NP_BWD, 80>), dim3(cell_grid_x(cell_bwd_kernel<CA_NP_BWD, 80>, lds, plan->n_cells, h, CA_WAVES_BWD), h),
+                       dim3(CA_WAVES_BWD * 64), lds, st, *plan, h, L, grad_out, q, k, v, out, table_q, table_k, table_v, pbuf, gsbuf, plane, grad_q,
+                       grad_k, grad_v);
     // the three table gradients read p / gs only
-    const int gx_q = max(1, min(cell_grid_x(N, h) * 2, div_up(N, CT_WAVES)));
-    const int gx_k = max(1, min(cell_grid_x(N, h) * 2, div_up(plan->n_keyslots, CT_WAVES)));
+    const int gx_t = max(1, min(2 * device_cus() / max(h, 1), div_up(plan->n_cells, CT_WAVES)));
+    const dim3 tgrid(gx_t, h), tblock(CT_WAVES * 64);
     if (L <= 64) {
         using G = CellTableGeo<4>;
-        hipLaunchKernelGGL((cell_table_grad_kernel<4, false>), dim3(gx_q, h), dim3(CT_WAVES * 64), G::lds_bytes(), st, *plan, N, h, L, gsbuf, plane,
-                           q, grad_table_q);
-        hipLaunchKernelGGL((cell_table_grad_kernel<4, false>), dim3(gx_q, h), dim3(CT_WAVES * 64), G::lds_bytes(), st, *plan, N, h, L, pbuf, plane,
-                           grad_out, grad_table_v);
-        hipLaunchKernelGGL((cell_table_grad_kernel<4, true>), dim3(gx_k, h), dim3(CT_WAVES * 64), G::lds_bytes(), st, *plan, plan->n_keyslots, h, L,
-                           gsbuf, plane, k, grad_table_k);
+        hipLaunchKernelGGL((cell_table_grad_kernel<4, false>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, q, grad_table_q);
+        hipLaunchKernelGGL((cell_table_grad_kernel<4, false>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, pbuf, plane, grad_out, grad_table_v);
+        hipLaunchKernelGGL((cell_table_grad_kernel<4, true>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, k, grad_table_k);
     } else {
         using G = CellTableGeo<5>;
-        hipLaunchKernelGGL((cell_table_grad_kernel<5, false>), dim3(gx_q, h), dim3(CT_WAVES * 64), G::lds_bytes(), st, *plan, N, h, L, gsbuf, plane,
-                           q, grad_table_q);
-        hipLaunchKernelGGL((cell_table_grad_kernel<5, false>), dim3(gx_q, h), dim3(CT_WAVES * 64), G::lds_bytes(), st, *plan, N, h, L, pbuf, plane,
-                           grad_out, grad_table_v);
-        hipLaunchKernelGGL((cell_table_grad_kernel<5, true>), dim3(gx_k, h), dim3(CT_WAVES * 64), G::lds_bytes(), st, *plan, plan->n_keyslots, h, L,
-                           gsbuf, plane, k, grad_table_k);
+        hipLaunchKernelGGL((cell_table_grad_kernel<5, false>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, q, grad_table_q);
+        hipLaunchKernelGGL((cell_table_grad_kernel<5, false>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, pbuf, plane, grad_out, grad_table_v);
+        hipLaunchKernelGGL((cell_table_grad_kernel<5, true>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, k, grad_table_k);
     }
     check_launch();
 }

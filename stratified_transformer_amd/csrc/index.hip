@@ -213,6 +213,30 @@ __global__ void cell_key_kernel(int N, int lbits, const int *__restrict__ s_clus
     keys[i] = ((unsigned long long)(unsigned)s_cluster[i] << lbits) | (unsigned)l_cluster[i];
     vals[i] = i;
 }
+// Cells are cut into pieces of at most `cap` queries (same key list, a tile of its own): a piece is the unit of work of
+// one wave, and the coarse stages have few intersections but many heads' worth of CUs to fill.
+__global__ void cell_run_start_kernel(int N, const int *__restrict__ flags, const int *__restrict__ rank_incl, int *__restrict__ run_start) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < N && flags[t]) run_start[rank_incl[t] - 1] = t;
+}
+__global__ void cell_split_flag_kernel(int N, int cap, const int *__restrict__ rank_incl, const int *__restrict__ run_start, int *__restrict__ flags) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < N && (t - run_start[rank_incl[t] - 1]) % cap == 0) flags[t] = 1;
+}
+// parents = the uncut cells: first piece of every parent (pieces of a parent are consecutive cell ids with the same key
+// list, so their tiles are one contiguous [sum n_q, n_k] tile: the key-side table gradient walks parents)
+__global__ void cell_parent_kernel(int N, const int *__restrict__ split_flags, const int *__restrict__ split_rank,
+                                   const int *__restrict__ parent_rank, const int *__restrict__ run_start, int *__restrict__ parent_first,
+                                   int *__restrict__ counts) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const int parent = parent_rank[t] - 1;
+    if (split_flags[t] && run_start[parent] == t) parent_first[parent] = split_rank[t] - 1;
+    if (t == N - 1) {
+        parent_first[parent + 1] = split_rank[t];
+        counts[4] = parent + 1;
+    }
+}
 // cell id of every sorted position; per cell: first sorted position, descriptor {dense start, dense count,
 // candidate start, candidate count}, key count and tile size (for the scans)
 __global__ void cell_describe_kernel(int N, const int *__restrict__ order, const int *__restrict__ flags, const int *__restrict__ rank_incl,
@@ -428,11 +452,12 @@ size_t pointops2_cell_plan_workspace_bytes(int N) {
 }
 
 // pass 1 (no host sync needed before it): cells of one block pattern from its small / large partitions and the
-// bucketed samples.  All outputs caller-allocated: cell_order, qcell, cell_perm [N]; cell_desc [4N]; cell_qstart,
-// cell_kbase, cell_pbase [N+2]; counts [4] = {cells, tile entries P, key slots K, largest key count}.
-void pointops2_cell_plan_count_launcher(int N, const int *s_cluster, const int *s_starts, const int *l_cluster,
+// bucketed samples; max_queries > 0 cuts cells into pieces of at most that many queries.  All outputs caller-allocated: cell_order, qcell, cell_perm [N]; cell_desc [4N]; cell_qstart,
+// cell_kbase, cell_pbase, parent_first [N+2]; counts [8] = {cells, tile entries P, key slots K, largest key count, parents}.
+void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_cluster, const int *s_starts, const int *l_cluster,
                                         const int *ls_starts, int *cell_order, int *qcell, int *cell_desc, int *cell_qstart,
-                                        int *cell_kbase, int *cell_pbase, int *cell_perm, int *counts, void *ws, size_t ws_bytes) {
+                                        int *cell_kbase, int *cell_pbase, int *cell_perm, int *parent_first, int *counts, void *ws,
+                                        size_t ws_bytes) {
     if (N <= 0) return;
     if (ws_bytes < pointops2_cell_plan_workspace_bytes(N)) { set_error("pointops2_cell_plan_count: workspace too small"); return; }
     hipStream_t st = state().stream;
@@ -450,7 +475,7 @@ void pointops2_cell_plan_count_launcher(int N, const int *s_cluster, const int *
     const int g = div_up(N, 256);
     int lbits = 1;
     while ((1ll << lbits) <= (long long)N) lbits++;  // window ids are < N
-    (void)hipMemsetAsync(counts, 0, 4 * sizeof(int), st);
+    (void)hipMemsetAsync(counts, 0, 8 * sizeof(int), st);
     hipLaunchKernelGGL(cell_key_kernel, dim3(g), dim3(256), 0, st, N, lbits, s_cluster, l_cluster, keys_in, vals_in);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const unsigned long long *)keys_in, keys_out, (const int *)vals_in,
                                                       cell_order, N, 0, 2 * lbits, st);
@@ -458,6 +483,17 @@ void pointops2_cell_plan_count_launcher(int N, const int *s_cluster, const int *
     hipLaunchKernelGGL(boundary_flag_kernel, dim3(g), dim3(256), 0, st, N, keys_out, flags);
     e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, N, st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    // (nk_of, tile_of and work_key are still free: first position of every uncut run, uncut rank, cut rank)
+    int *prank = tile_of, *srank = reinterpret_cast<int *>(work_key);
+    hipLaunchKernelGGL(cell_run_start_kernel, dim3(g), dim3(256), 0, st, N, flags, rank, nk_of);
+    (void)hipMemcpyAsync(prank, rank, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st);
+    if (max_queries > 0) {
+        hipLaunchKernelGGL(cell_split_flag_kernel, dim3(g), dim3(256), 0, st, N, max_queries, rank, nk_of, flags);
+        e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, N, st);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    }
+    (void)hipMemcpyAsync(srank, rank, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(cell_parent_kernel, dim3(g), dim3(256), 0, st, N, flags, srank, prank, nk_of, parent_first, counts);
     hipLaunchKernelGGL(cell_describe_kernel, dim3(g), dim3(256), 0, st, N, cell_order, flags, rank, s_cluster, s_starts, l_cluster, ls_starts,
                        qcell, cell_qstart, cell_desc, nk_of, counts);
     // (vals_in is free again: the ids of the work-order sort)

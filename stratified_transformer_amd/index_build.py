@@ -189,8 +189,8 @@ def _f32(x):
 
 class CellPlanStruct(ctypes.Structure):
     """pointops2_cell_plan of include/pointops2_hip.h"""
-    _fields_ = [("n_points", ctypes.c_int), ("n_pairs", ctypes.c_int), ("n_keyslots", ctypes.c_int),
-                ("counts", ctypes.c_void_p), ("cell_perm", ctypes.c_void_p), ("cell_qstart", ctypes.c_void_p),
+    _fields_ = [("n_points", ctypes.c_int), ("n_cells", ctypes.c_int), ("n_parents", ctypes.c_int), ("n_pairs", ctypes.c_int),
+                ("n_keyslots", ctypes.c_int), ("counts", ctypes.c_void_p), ("parent_first", ctypes.c_void_p), ("cell_perm", ctypes.c_void_p), ("cell_qstart", ctypes.c_void_p),
                 ("cell_kbase", ctypes.c_void_p), ("cell_pbase", ctypes.c_void_p), ("cell_order", ctypes.c_void_p),
                 ("qcell", ctypes.c_void_p), ("cell_keys", ctypes.c_void_p), ("kcell", ctypes.c_void_p), ("relp", ctypes.c_void_p)]
 
@@ -205,7 +205,9 @@ class CellPlan:
     n_keyslots: int                # K = sum n_k
     nk_max: int
     table_rows: int                # L the packed rel-pos indices were clamped to
-    counts: torch.Tensor           # [4] i32
+    n_parents: int                 # cells before the cut into pieces of at most cell_max_queries queries
+    counts: torch.Tensor           # [8] i32
+    parent_first: torch.Tensor     # [N+2] i32
     cell_perm: torch.Tensor        # [N] i32
     cell_desc: torch.Tensor        # [N,4] i32 {dense start, dense count, candidate start, candidate count}
     cell_qstart: torch.Tensor      # [N+2] i32
@@ -221,22 +223,32 @@ class CellPlan:
     def c_arg(self):
         from ._lib import ptr
         if self.struct is None:
-            self.struct = CellPlanStruct(self.n_points, self.n_pairs, self.n_keyslots, ptr(self.counts), ptr(self.cell_perm), ptr(self.cell_qstart),
+            self.struct = CellPlanStruct(self.n_points, self.n_cells, self.n_parents, self.n_pairs, self.n_keyslots, ptr(self.counts),
+                                         ptr(self.parent_first), ptr(self.cell_perm), ptr(self.cell_qstart),
                                          ptr(self.cell_kbase), ptr(self.cell_pbase), ptr(self.cell_order), ptr(self.qcell), ptr(self.cell_keys),
                                          ptr(self.kcell), ptr(self.relp))
         return ctypes.byref(self.struct)
 
     def tensors(self):
-        return (self.counts, self.cell_perm, self.cell_desc, self.cell_qstart, self.cell_kbase, self.cell_pbase, self.cell_order, self.qcell,
+        return (self.counts, self.parent_first, self.cell_perm, self.cell_desc, self.cell_qstart, self.cell_kbase, self.cell_pbase, self.cell_order, self.qcell,
                 self.cell_keys, self.kcell, self.relp)
 
 
-def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_table_rows=None):
+def cell_query_cap(n_points, heads):
+    """Queries per cell piece: small enough that cells x heads fill the chip's resident waves several times over."""
+    cap = 32
+    while cap > 4 and n_points * heads < 6000 * cap:
+        cap //= 2
+    return cap
+
+
+def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_table_rows=None, cell_max_queries=0):
     """Even and odd block index of one stage, built by the HIP kernels of csrc/index.hip.
 
     xyz [N,3] f32 (GPU), offset [b] i32, downsample_idx [m] i32 -> (BlockIndex even, BlockIndex odd),
     bit-identical to build_block_index() on the same inputs.  cell_table_rows = L: also the cell plan of both
-    patterns (BlockIndex.cells) for fused.cell_attention, with the rel-pos indices clamped to [0, L)."""
+    patterns (BlockIndex.cells) for fused.cell_attention, with the rel-pos indices clamped to [0, L); cell_max_queries > 0
+    cuts cells into pieces of at most that many queries (cell_query_cap)."""
     import numpy as np
     from . import _lib
     from ._lib import ptr
@@ -284,19 +296,20 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
             if cell_table_rows is not None:
                 cws_bytes = int(l.pointops2_cell_plan_workspace_bytes(N))
                 cws = ws if cws_bytes <= ws_bytes else torch.empty(cws_bytes, dtype=torch.uint8, device=dev)
-                cells = dict(counts=torch.empty(4, **i32), cell_perm=torch.empty(N, **i32), cell_desc=torch.empty((N, 4), **i32),
+                cells = dict(counts=torch.empty(8, **i32), parent_first=torch.empty(N + 2, **i32), cell_perm=torch.empty(N, **i32), cell_desc=torch.empty((N, 4), **i32),
                              cell_qstart=torch.empty(N + 2, **i32), cell_kbase=torch.empty(N + 2, **i32), cell_pbase=torch.empty(N + 2, **i32),
                              cell_order=torch.empty(N, **i32), qcell=torch.empty(N, **i32))
-                call("pointops2_cell_plan_count_launcher", N, ptr(s.cluster), ptr(s.starts), ptr(lg.cluster), ptr(ls_starts),
+                call("pointops2_cell_plan_count_launcher", N, int(cell_max_queries), ptr(s.cluster), ptr(s.starts), ptr(lg.cluster), ptr(ls_starts),
                      ptr(cells["cell_order"]), ptr(cells["qcell"]), ptr(cells["cell_desc"]), ptr(cells["cell_qstart"]), ptr(cells["cell_kbase"]),
-                     ptr(cells["cell_pbase"]), ptr(cells["cell_perm"]), ptr(cells["counts"]), ptr(cws), max(cws_bytes, ws_bytes))
+                     ptr(cells["cell_pbase"]), ptr(cells["cell_perm"]), ptr(cells["parent_first"]), ptr(cells["counts"]), ptr(cws),
+                     max(cws_bytes, ws_bytes))
             pending.append((s, lg, ls, ls_starts, wc, offsets, cells))
         # host sync 2: M of both patterns (and the cell plans' totals)
         if cell_table_rows is None:
             totals = [(m, None) for m in torch.stack([p[5][N] for p in pending]).tolist()]
         else:
             flat = torch.cat([torch.cat([p[5][N:N + 1], p[6]["counts"]]) for p in pending]).tolist()
-            totals = [(flat[5 * i], flat[5 * i + 1:5 * i + 5]) for i in range(len(pending))]
+            totals = [(flat[9 * i], flat[9 * i + 1:9 * i + 6]) for i in range(len(pending))]
         for (s, lg, ls, ls_starts, wc, offsets, cells), (M, ccounts) in zip(pending, totals):
             index_0, index_1 = torch.empty(M, **i32), torch.empty(M, **i32)
             rel = torch.empty((M, 3), **i32)
@@ -305,13 +318,13 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
             counts = offsets[1:] - offsets[:-1]
             plan = None
             if cells is not None:
-                n_cells, P, K, nk_max = ccounts
+                n_cells, P, K, nk_max, n_parents = ccounts
                 if P < 0 or P >= 2 ** 31 - 1:
                     raise RuntimeError("cell plan: more than 2^31 tile entries")
                 cell_keys, kcell, relp = torch.empty(max(K, 1), **i32), torch.empty(max(K, 1), **i32), torch.empty(max(P, 1), **i32)
                 call("pointops2_cell_plan_fill_launcher", N, ptr(xyz), float(w32), _f32(quant_size), int(cell_table_rows), ptr(s.order), ptr(ls),
                      ptr(wc), ptr(cells["cell_order"]), ptr(cells["qcell"]), ptr(cells["cell_qstart"]), ptr(cells["cell_desc"]),
                      ptr(cells["cell_kbase"]), ptr(cells["cell_pbase"]), ptr(cell_keys), ptr(kcell), ptr(relp))
-                plan = CellPlan(N, n_cells, P, K, nk_max, int(cell_table_rows), cell_keys=cell_keys, kcell=kcell, relp=relp, **cells)
+                plan = CellPlan(N, n_cells, P, K, nk_max, int(cell_table_rows), n_parents, cell_keys=cell_keys, kcell=kcell, relp=relp, **cells)
             out.append(BlockIndex(index_0, index_1, offsets, counts.max(), rel, None, plan))
     return out[0], out[1], parts

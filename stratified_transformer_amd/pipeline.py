@@ -298,7 +298,8 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         with torch.cuda.stream(idx_s):
             if use_hip_index:
                 even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds,
-                                         table_rows(st) if (cells or fused == "cell") else None)
+                                         table_rows(st) if (cells or fused == "cell") else None,
+                                         index_build.cell_query_cap(x.shape[0], st.num_heads))
             else:
                 parts = timer.run("index/partition", index_build.stage_partitions, x, off, st.window_size)
                 even = timer.run("index/pairs", index_build.build_block_index, x, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)

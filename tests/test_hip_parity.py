@@ -684,13 +684,13 @@ def test_fused_window_attention_matches_the_operator_chain(P, case):
 
 
 # ---- window-centric ("cell") attention: csrc/index.hip cells + csrc/cell_attn.hip ----------------------
-def _cell_scene(n, nbatch, w, quant, seed, L):
+def _cell_scene(n, nbatch, w, quant, seed, L, cap=0):
     from stratified_transformer_amd import index_build, scene
     sizes = [n // nbatch + (1 if i < n % nbatch else 0) for i in range(nbatch)]
     xyz_np, offset = scene.make_batch(sizes, seed=seed)
     rng = np.random.default_rng(seed)
     ds = np.sort(rng.permutation(n)[: n // 8 + nbatch]).astype(np.int32)
-    even, odd, _ = index_build.stage_index_hip(dev(xyz_np), dev(offset), w, quant, dev(ds), cell_table_rows=L)
+    even, odd, _ = index_build.stage_index_hip(dev(xyz_np), dev(offset), w, quant, dev(ds), cell_table_rows=L, cell_max_queries=cap)
     return xyz_np, offset, even, odd
 
 
@@ -711,15 +711,17 @@ def _expand_cells(plan):
     return allp[np.argsort(allp[:, 0], kind="stable")]
 
 
-@pytest.mark.parametrize("n,nbatch,w,quant", [(6000, 1, 0.16, 0.01), (5000, 3, 0.32, 0.02), (900, 2, 0.64, 0.04)])
-def test_cell_plan_is_the_pair_list(n, nbatch, w, quant):
+@pytest.mark.parametrize("n,nbatch,w,quant,cap", [(6000, 1, 0.16, 0.01, 0), (5000, 3, 0.32, 0.02, 8), (900, 2, 0.64, 0.04, 4), (6000, 1, 0.16, 0.01, 16)])
+def test_cell_plan_is_the_pair_list(n, nbatch, w, quant, cap):
     """Every (query, key, rel-pos index) of the CSR pair list - itself bit-identical to the oracle's restatement of
     get_indice_pairs (test_index_build_hip_matches_oracle_and_torch_path) - appears exactly once in the cell tiles, in the
     same per-query order; each query and each cell id exactly once; the work order is a permutation, largest tile first."""
     L = 2 * int((2 * w + 1e-4) // quant)
-    _, _, even, odd = _cell_scene(n, nbatch, w, quant, seed=n, L=L)
+    _, _, even, odd = _cell_scene(n, nbatch, w, quant, seed=n, L=L, cap=cap)
     for blk in (even, odd):
         plan = blk.cells
+        if cap:
+            assert np.diff(_np(plan.cell_qstart)[: plan.n_cells + 1]).max() <= cap
         got = _expand_cells(plan)
         i0, i1, rel = _np(blk.index_0).astype(np.int64), _np(blk.index_1).astype(np.int64), np.clip(_np(blk.rel_idx), 0, L - 1)
         assert got.shape[0] == i0.shape[0]
@@ -730,6 +732,14 @@ def test_cell_plan_is_the_pair_list(n, nbatch, w, quant):
         tiles = np.diff(_np(plan.cell_pbase)[: plan.n_cells + 1])
         assert np.all(np.diff(tiles[perm]) <= 0) and tiles.sum() == plan.n_pairs
         assert np.diff(_np(plan.cell_kbase)[: plan.n_cells + 1]).max() == plan.nk_max
+        # parents: the uncut cells; the pieces of a parent are consecutive cell ids with one key list (contiguous tiles)
+        pf, kb, keys = _np(plan.parent_first)[: plan.n_parents + 1], _np(plan.cell_kbase), _np(plan.cell_keys)
+        assert pf[0] == 0 and pf[-1] == plan.n_cells and np.all(np.diff(pf) > 0)
+        if not cap:
+            assert plan.n_parents == plan.n_cells
+        for a, b in zip(pf[:-1], pf[1:]):
+            for piece in range(a + 1, b):
+                assert np.array_equal(keys[kb[piece]: kb[piece + 1]], keys[kb[a]: kb[a + 1]])
 
 
 def _oracle_attention(p, i1, offs, rel, go):
@@ -748,11 +758,11 @@ def test_cell_attention_matches_the_oracle(case):
     """fused.cell_attention (forward and all six gradients) against the oracle's operator chain on the CSR pair list of the
     same block pattern, even and odd.  Tolerance: the north_star's 1e-3 is the bar; measured differences are ~1e-6."""
     from stratified_transformer_amd import fused
-    n, nbatch, w, quant, h = dict(s3dis_stage0_h3=(5000, 1, 0.16, 0.01, 3), batch3_h6_L64=(4000, 3, 0.32, 0.02, 6),
-                                  scannet_L80_h3=(4000, 1, 0.1, 0.005, 3), big_cells_two_chunks_h2=(3000, 1, 0.32, 0.02, 2),
-                                  coarse_h12=(700, 2, 0.64, 0.04, 12))[case]
+    n, nbatch, w, quant, h, cap = dict(s3dis_stage0_h3=(5000, 1, 0.16, 0.01, 3, 0), batch3_h6_L64=(4000, 3, 0.32, 0.02, 6, 16),
+                                       scannet_L80_h3=(4000, 1, 0.1, 0.005, 3, 32), big_cells_two_chunks_h2=(3000, 1, 0.32, 0.02, 2, 0),
+                                       coarse_h12=(700, 2, 0.64, 0.04, 12, 4))[case]
     L = 2 * int((2 * w + 1e-4) // quant)
-    xyz_np, offset, even, odd = _cell_scene(n, nbatch, w, quant, seed=7 + h, L=L)
+    xyz_np, offset, even, odd = _cell_scene(n, nbatch, w, quant, seed=7 + h, L=L, cap=cap)
     rng = np.random.default_rng(h)
     p = dict(q=rng.standard_normal((n, h, 16), dtype=np.float32), k=rng.standard_normal((n, h, 16), dtype=np.float32),
              v=rng.standard_normal((n, h, 16), dtype=np.float32))

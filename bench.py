@@ -1,37 +1,45 @@
 #!/usr/bin/env python
 """bench.py — points/sec through StratifiedAttention fwd+bwd on a 100k-point scene (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--shard]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One step = one pass of the hot path over one synthetic S3DIS-like scene of 100 000 points per GPU
-(stratified_transformer_amd/pipeline.py: for each of the 4 stages of s3dis_stratified_transformer.yaml
-the index build incl. stratified FPS, depth x [A1,A2,add,A3,A4] forward+backward, TransitionDown FPS +
-kNN(16), Upsample kNN(3)).  All inputs are resident in HBM before the timed region.  The K timed passes run with
---in-flight L (default 3-5, by the length of the run) batches in flight: the sampling chains of the next L-1 batches - functions of the
-coordinates alone - are queued ahead of this batch's index builds and attention blocks, forward+backward of
-consecutive batches strictly in order (pipeline.passes_in_flight); the same K passes one at a time are reported
-as `single_batch`, and `same_results_as_single_pass` says that both give the same tensors.  N>1: one process
-per GPU, one scene per rank (scenes are independent units: windows never cross a batch element, so the
-path shards with no data-path collective) -> weak scaling; value = all ranks' points / max-over-ranks time.
+One step = one pass of the hot path over one synthetic S3DIS-like scene of 100 000 points (SURVEY.md 8d;
+stratified_transformer_amd/pipeline.py): for each of the 4 stages of s3dis_stratified_transformer.yaml the index build
+incl. stratified FPS, depth x attention block forward+backward, TransitionDown FPS + kNN(16), Upsample kNN(3).  All
+inputs are resident in HBM before the timed region.
+
+What is timed, and what the line calls it:
+  single_pass   K passes one after the other, each complete before the next starts (the unit of SURVEY 8d; `value`):
+                  .cell          attention blocks = fused.cell_attention (window-centric kernels, csrc/cell_attn.hip)   <- value
+                  .operator_api  attention blocks = the reference's five operators (A1, A2, add, A3, A4), what an
+                                 unmodified model/stratified_transformer.py calls
+  in_flight     the same K passes with --in-flight L (default 4, fixed) batches in flight: the sampling chains of the
+                next L-1 batches - functions of the coordinates alone - queued ahead; forward+backward of consecutive
+                batches strictly in order (pipeline.passes_in_flight).  A stated throughput configuration, not `value`.
+N > 1 ranks (one process per GPU; `--gpus N` without a launcher starts the N ranks itself, before any GPU call):
+  default       one scene per rank, no data-path collective: "scaling": "weak", value = N x 100 000 / max-over-ranks time
+  --shard       ONE scene over the N ranks (queries sharded by pair count, all-gather of k/v rows, reduce-scatter
+                of their gradients, all-reduce of the table gradients over RCCL): "scaling": "strong"
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     : the dominant kernel of the timed region, algorithmic bytes / its live-measured mean
-                 launch duration (HIP events on the launch stream) vs the 8 TB/s HBM peak
-  cpu_baseline : the oracle (CPU port of the reference kernels, OpenMP) on the same step, same box
+  roofline      the attention kernels of the timed region (the dominant group once FPS is off the critical path; FPS is
+                latency-bound and reported as steps/s in `fps`): SURVEY 8(d)'s algorithmic bytes of every block of a step,
+                summed, over the HIP-event time of those blocks inside the timed region, vs the 8 TB/s HBM peak;
+                `traffic` = PMC bytes beyond L2 per step for the same kernels (profiles/, tools/pmc_traffic.py)
+  cpu_baseline  the oracle (CPU port of the reference kernels, OpenMP) on the same step on this box's host cores
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
-# Hardware queues of the HIP runtime (read when the runtime initialises, i.e. at the first device call below): with
-# the default of 4 the ~15 streams of the lanes share queues and a sampler kernel of one batch blocks unrelated
-# kernels of another that happen to sit behind it in the same queue.
+# Hardware queues of the HIP runtime (read when the runtime initialises, i.e. at the first device call): with the default
+# of 4 the ~15 streams of the in-flight lanes share queues and a sampler kernel of one batch blocks unrelated kernels of
+# another that happen to sit behind it in the same queue.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -39,42 +47,60 @@ sys.path.insert(0, ROOT)
 
 N_POINTS = 100_000
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+IN_FLIGHT_DEFAULT = 4
 
 
-def algorithmic_bytes(op, info):
-    """SURVEY.md §8(d) per-op compulsory bytes (fp32/int32), for one launch of `op` at stage `info`."""
-    if op.startswith("fps/"):
-        # per iteration: read xyz (12 B) + min-dist (4 B) and write min-dist (4 B) for every point
-        return 20 * info["n"] * max(info["m"] - 1, 0)
-    if op.startswith("knn/"):
-        return 12 * info["n"] + 12 * info["m"] + 8 * info["m"] * info["k"]
-    N, M, C, h = info["N"], info["M"], info["C"], info["h"]
-    if op == "attn_fwd/A1":
-        return 8 * N * C + 4 * M + 4 * N + 4 * M * h
-    if op == "attn_fwd/A2":
-        return 8 * N * C + 16 * M + 4 * N + 4 * M * h
-    if op == "attn_fwd/A4":
-        return 8 * N * C + 16 * M + 4 * N + 4 * M * h
-    if op == "attn_fwd/A3":
-        return 8 * M * h + 4 * N
-    if op == "attn_fwd/add":
-        return 12 * M * h
-    if op == "attn_bwd":
-        return 44 * N * C + 12 * N + 36 * M + 16 * M * h + 16 * M * h  # + A3 backward (y, gy read; gx write) + add
-    return None
+# ---------------------------------------------------------------------------------------------------------------------
+# unique compulsory bytes of one attention block under the five-operator boundary (fp32 / int32)
+# ---------------------------------------------------------------------------------------------------------------------
+def attention_bytes(N, M, C, h):
+    fwd = 24 * N * C + 12 * N + 36 * M + 12 * M * h      # A1 + A2 + A4 forward
+    fwd_glue = 20 * M * h + 8 * M                        # add (12 Mh) + scatter_softmax (8 Mh + 8 M)
+    bwd = 44 * N * C + 12 * N + 36 * M + 16 * M * h      # A1 + A2 + A4 backward
+    return dict(fwd=fwd, fwd_glue=fwd_glue, bwd=bwd)
+
+
+def step_attention_bytes(cfg, results):
+    tot = dict(fwd=0, fwd_glue=0, bwd=0)
+    per_stage = []
+    for r in results:
+        st = cfg.stages[r["stage"]]
+        for b in range(st.depth):
+            M = r["M_even"] if b % 2 == 0 else r["M_odd"]
+            for k, v in attention_bytes(r["n"], M, st.channels, st.num_heads).items():
+                tot[k] += v
+        per_stage.append(dict(stage=r["stage"], N=r["n"], M_even=r["M_even"], M_odd=r["M_odd"], C=st.channels, h=st.num_heads, depth=st.depth))
+    return tot, per_stage
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run), before this
+    process touches the GPU, and return their exit code (non-zero if any rank fails or does not join)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def run_gpu(args, rank, world):
+    import numpy as np
+    import torch
     from stratified_transformer_amd import pipeline, scene
-    # (the modulo only matters for a rehearsal of the N>1 path with several ranks on a one-GPU box)
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    ndev = torch.cuda.device_count()
+    if world > ndev and not os.environ.get("BENCH_ALLOW_SHARED_GPU"):
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s) visible (BENCH_ALLOW_SHARED_GPU=1 rehearses the N>1 path on fewer)")
+    dev = torch.device("cuda", local % max(ndev, 1))
     torch.cuda.set_device(dev)
     cfg = pipeline.s3dis_config()
-    xyz_np = scene.make_room(N_POINTS, seed=rank)
+    shard = (rank, world) if (args.shard and world > 1) else None
+    xyz_np = scene.make_room(N_POINTS, seed=0 if shard else rank)
     xyz = torch.from_numpy(xyz_np).to(dev)
     offset = torch.tensor([N_POINTS], dtype=torch.int32, device=dev)
-
-    states, results = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + rank)  # creates resident tensors
+    HOST_OFFS = [[N_POINTS]]  # (the host copy of the batch offsets a data loader has)
 
     def barrier():
         torch.cuda.synchronize()
@@ -89,63 +115,66 @@ def run_gpu(args, rank, world):
             return float(t.item())
         return seconds
 
-    # One lane = one set of streams + one set of resident state tensors.  With L lanes the sampling chains (FPS, kNN:
-    # functions of the coordinates alone, one workgroup wide for most of their time) of the next L-1 batches are
-    # queued in front of the index builds and attention blocks of batch k, the way a training loop prefetches its
-    # data-side geometry; the forward+backward of consecutive batches stay strictly in order (an event between
-    # them, where the optimizer step would sit).  Same kernels, same results as a pass on its own (checked below).
-    HOST_OFFS = [[N_POINTS]]  # (the host copy of the batch offsets a data loader has)
-    lanes = []
-    for li in range(args.in_flight):
-        lane_stream = torch.cuda.Stream(dev)
-        lane_stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(lane_stream):
-            lane_states, _ = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + rank, lane=li)
-        lanes.append((lane_stream, lane_states))
-    barrier()
-    if args.warmup > 0:
-        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.warmup, offset_host_list=HOST_OFFS)
-    # In the timed region only the sampler launches (the dominant op, 7 per pass) carry event pairs; the
-    # per-op table of all components comes from passes run again afterwards with events around every
-    # op (~270 event records per pass are host work, and the late stages are close to host-bound).
-    live = pipeline.Timer(True, only=("fps/",))
-    barrier()
-    t0 = time.perf_counter()
-    last = pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, timer=live, offset_host_list=HOST_OFFS)
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    out = dict(cfg=cfg, xyz_np=xyz_np, dev=dev)
+    # resident synthetic tensors (q/k/v/tables/grad_out stand in for the Linear layers); created once, not timed
+    states, results = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + (0 if shard else rank), fused=False if shard else "cell", shard=shard)
 
-    # one batch at a time (the latency of a pass on its own), on the default stream
-    pipeline.scene_pass(xyz, offset, cfg, states)
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        states, results = pipeline.scene_pass(xyz, offset, cfg, states)
-    barrier()
-    single_elapsed = max_over_ranks(time.perf_counter() - t1)
-    same = True
-    for lane_results in last:
-        if lane_results is None:
-            continue
-        for a, b in zip(results, lane_results):
-            same = same and torch.equal(a["downsample_idx"], b["downsample_idx"]) and torch.equal(a["even"].index_1, b["even"].index_1) \
-                and torch.equal(a["odd"].rel_idx, b["odd"].rel_idx) and torch.equal(a["out"], b["out"])
+    def single_pass_leg(fused):
+        nonlocal states
+        st, res = states, None
+        for _ in range(max(args.warmup, 1)):
+            st, res = pipeline.scene_pass(xyz, offset, cfg, st, fused=fused, shard=shard)
+        live = pipeline.Timer(True, only=("attn", "fps/", "comm/"))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st, res = pipeline.scene_pass(xyz, offset, cfg, st, live, fused=fused, shard=shard)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        states = st
+        return dict(elapsed=elapsed, live=live, results=res)
+
+    out["single_ops"] = single_pass_leg(False)
+    # (the sharded scene runs the operator path: sharding.py cuts the CSR pair list by query range; a cell plan per query range is next)
+    out["single_cell"] = out["single_ops"] if shard else single_pass_leg("cell")
+    out["results"], out["states"] = out["single_ops"]["results"], states
+
+    # every component, from passes run again with events around every op (not the timed region)
     timer = pipeline.Timer(True)
     for _ in range(args.steps):
-        states, results = pipeline.scene_pass(xyz, offset, cfg, states, timer)
+        pipeline.scene_pass(xyz, offset, cfg, states, timer, fused=False if shard else "cell", shard=shard)
     barrier()
-    # the optional fused module on the same passes: reported beside the headline, which stays on
-    # the reference's operator API
-    fused_elapsed = None
-    if not args.no_fused:
-        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, min(args.warmup, 2) or 1, fused=True, offset_host_list=HOST_OFFS)
+    out["timer"] = timer
+
+    if not shard and args.in_flight > 1:
+        lanes = []
+        for li in range(args.in_flight):
+            lane_stream = torch.cuda.Stream(dev)
+            lane_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(lane_stream):
+                lane_states, _ = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + rank, lane=li, fused="cell")
+            lanes.append((lane_stream, lane_states))
         barrier()
-        t2 = time.perf_counter()
-        pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=True, offset_host_list=HOST_OFFS)
-        barrier()
-        fused_elapsed = max_over_ranks(time.perf_counter() - t2)
-    return dict(cfg=cfg, xyz_np=xyz_np, states=states, results=results, timer=timer, live=live, elapsed=elapsed, fused_elapsed=fused_elapsed,
-                single_elapsed=single_elapsed, inflight_same=bool(same), dev=dev)
+
+        def in_flight_leg(fused):
+            pipeline.passes_in_flight([xyz], [offset], cfg, lanes, max(args.warmup, 1), fused=fused, offset_host_list=HOST_OFFS)
+            barrier()
+            t0 = time.perf_counter()
+            last = pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=fused, offset_host_list=HOST_OFFS)
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0), last
+
+        out["inflight_cell"], last = in_flight_leg("cell")
+        out["inflight_ops"], last_ops = in_flight_leg(False)
+        same = True
+        for lane_results in last_ops:
+            if lane_results is None:
+                continue
+            for a, b in zip(out["results"], lane_results):
+                same = same and torch.equal(a["downsample_idx"], b["downsample_idx"]) and torch.equal(a["even"].index_1, b["even"].index_1) \
+                    and torch.equal(a["odd"].rel_idx, b["odd"].rel_idx) and torch.equal(a["out"], b["out"])
+        out["inflight_same"] = bool(same)
+    return out
 
 
 def component_table(timer, steps):
@@ -155,122 +184,127 @@ def component_table(timer, steps):
     return comp
 
 
-def roofline(comp, run, among=None):
-    """dominant timed op (optionally only among the ops whose name starts with `among`) -> achieved algorithmic GB/s"""
-    cfg, results = run["cfg"], run["results"]
-    name = max((k for k in comp if among is None or k.startswith(among)), key=lambda k: comp[k]["ms_per_step"])
-    r0 = results[0]
-    st0 = cfg.stages[0]
-    info = dict(N=r0["n"], M=(r0["M_even"] + r0["M_odd"]) // 2, C=st0.channels, h=st0.num_heads)
-    note = ""
-    if name.startswith("fps/"):
-        # per-launch mean over the 3-4 launches per step: weight bytes by every launch of that op
-        ns = [r["n"] for r in results]
-        if name == "fps/stratified":
-            launches = [dict(n=n, m=n // cfg.downsample_scale + 1) for n in ns]
-        else:
-            launches = [dict(n=n, m=int(n * cfg.ratio) + 1) for n in ns[:-1]]
-        bytes_per_launch = float(np.mean([algorithmic_bytes(name, l) for l in launches]))
-        note = "mean over the op's launches in one step (one per stage); latency-bound: %d dependent iterations" % sum(l["m"] for l in launches)
-    elif name.startswith("knn/") or algorithmic_bytes(name, info) is None:  # (an op without a byte model can only
-        bytes_per_launch = None                                              # dominate under a serializing profiler)
-    else:
-        # attention ops run depth times per stage; bytes are summed over all launches of a step / launches
-        tot, cnt = 0, 0
-        for si, r in enumerate(results):
-            st = cfg.stages[r["stage"]]
-            for b in range(st.depth):
-                M = r["M_even"] if b % 2 == 0 else r["M_odd"]
-                tot += algorithmic_bytes(name, dict(N=r["n"], M=M, C=st.channels, h=st.num_heads))
-                cnt += 1
-        bytes_per_launch = tot / cnt
-        note = "mean over the op's %d launches per step (all stages/blocks)" % cnt
-    if bytes_per_launch is None:
-        return dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
-                    note="no byte model for this op (kNN is VALU/latency-bound; see DESIGN.md)")
-    dur_s = comp[name]["ms_per_call"] / 1e3
-    achieved = bytes_per_launch / dur_s / 1e9
-    # HBM-side bytes per launch from the committed PMC passes (tools/pmc_traffic.py: separate FETCH_SIZE and
-    # WRITE_SIZE runs of this command, (2 x FETCH_SIZE + WRITE_SIZE) x 1024): the group's bytes per pass over the
-    # group's op launches per pass
+def attention_roofline(leg, run, steps, label):
+    """SURVEY 8(d) bytes of all attention blocks of a step over their HIP-event time inside the timed region."""
+    comp = component_table(leg["live"], steps)
+    fwd_ms = sum(v["ms_per_step"] for k, v in comp.items() if k.startswith("attn_fwd"))
+    bwd_ms = sum(v["ms_per_step"] for k, v in comp.items() if k.startswith("attn_bwd"))
+    by, per_stage = step_attention_bytes(run["cfg"], leg["results"])
+    fwd_bytes = by["fwd"] + by["fwd_glue"]
+    total = fwd_bytes + by["bwd"]
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
-        group = name.split("/")[0] if name.split("/")[0] in ("fps", "knn") else name.split("/")[0]
-        per_pass = json.load(open(pmc)).get("bytes_per_pass_by_group", {}).get(group)
-        launches = sum(c["calls_per_step"] for k, c in comp.items() if k.split("/")[0] == group)
-        if per_pass and launches:
-            traffic = int(per_pass / launches)
-    return dict(bound="hbm", kernel=name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, algorithmic_bytes_per_launch=int(bytes_per_launch),
-                mean_launch_ms=round(comp[name]["ms_per_call"], 4), note=note)
+        try:
+            groups = json.load(open(pmc)).get("bytes_per_pass_by_group", {})
+            key = "cell_attn" if label == "cell" else "attn"
+            if key + "_fwd" in groups and key + "_bwd" in groups:
+                traffic = int(groups[key + "_fwd"] + groups[key + "_bwd"])
+        except (ValueError, OSError):
+            traffic = None
+    ach = total / ((fwd_ms + bwd_ms) / 1e3) / 1e9 if fwd_ms + bwd_ms > 0 else None
+    return dict(bound="hbm", kernel="attention blocks, forward+backward (%s)" % label, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+                algorithmic_bytes_per_step=int(total), attention_ms_per_step=round(fwd_ms + bwd_ms, 3),
+                forward=dict(bytes=int(fwd_bytes), ms=round(fwd_ms, 3), frac=round(fwd_bytes / (fwd_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if fwd_ms else None,
+                             formula="sum over blocks of 24NC+12N+36M+12Mh (A1,A2,A4) + 20Mh+8M (add, softmax)"),
+                backward=dict(bytes=int(by["bwd"]), ms=round(bwd_ms, 3), frac=round(by["bwd"] / (bwd_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if bwd_ms else None,
+                              formula="sum over blocks of 44NC+12N+36M+16Mh"),
+                note="bytes: SURVEY 8(d) unique compulsory bytes under the five-operator boundary, every block of every stage of one step; "
+                     "time: HIP events around each block's forward and backward on the launch stream, inside the timed region; "
+                     "traffic: FETCH_SIZE/WRITE_SIZE passes of the same kernels per step (profiles/pmc_traffic.json), null until collected")
+
+
+def fps_report(leg, run, steps):
+    comp = component_table(leg["live"], steps)
+    ms = sum(v["ms_per_step"] for k, v in comp.items() if k.startswith("fps/"))
+    cfg, results = run["cfg"], leg["results"]
+    n_steps = sum((r["n"] // cfg.downsample_scale + 1) for r in results) + sum(int(r["n"] * cfg.ratio) + 1 for r in results[:-1])
+    # dependent sampling steps that are not an identity prefix verified in parallel: the first stage's n*ratio+1
+    seq = int(results[0]["n"] * cfg.ratio) + 1
+    evals = sum(float(r["n"]) * (int(r["n"] * cfg.ratio) + 1) for r in results[:-1]) + float(results[-1]["n"]) * (results[-1]["n"] // cfg.downsample_scale + 1)
+    return dict(ms_per_step=round(ms, 3), samples_per_pass=int(n_steps), sequential_steps_per_pass=seq,
+                steps_per_s=round(seq / (ms / 1e3), 1) if ms else None,
+                reference_distance_evals_per_s=round(evals / (ms / 1e3), 1) if ms else None,
+                note="latency-bound: one workgroup per batch element; steps/s = dependent sampling steps of stage 0 over the event time of all "
+                     "sampler launches of a pass; the reference's formulation would evaluate n distances per step (reference_distance_evals_per_s "
+                     "prices the run at that count; the bucketed kernel evaluates ~30x fewer); no HBM roofline is claimed for it")
 
 
 def cpu_baseline(run):
-    """The oracle (CPU port of the reference's kernels, OpenMP over all host cores) on one full step of
-    the same scene; also the full-size integer parity check of the GPU results."""
+    """The oracle (CPU port of the reference's kernels, OpenMP) on the same step of the same scene: 2 warm-ups + median of 5
+    on all host cores of the box, plus a 1-thread figure on a stated sub-sample."""
+    import numpy as np
+    import torch
     from oracle import index_ref, pointops_ref as ref
-    cfg, results, states = run["cfg"], run["results"], run["states"]
-    ref.set_num_threads(ref.host_cores(16))  # a one-GPU box owns 16 host cores; OpenMP would otherwise spawn one thread per visible CPU
-    cores = ref.num_threads()
-    parity = {}
-    t_total = 0.0
-    xyz = run["xyz_np"]
-    offset = np.array([N_POINTS], np.int32)
-    for r in results:
-        si = r["stage"]
-        st = cfg.stages[si]
+    cfg, states = run["cfg"], run["states"]
+    cores = ref.host_cores(16)  # a one-GPU box owns 16 host cores; OpenMP would otherwise spawn one thread per visible CPU
+    ref.set_num_threads(cores)
+    # host copies of the resident tensors and the point cloud of every stage (not CPU-path work: outside the timing)
+    host = []
+    xyz, offset = run["xyz_np"], np.array([N_POINTS], np.int32)
+    for si, st in enumerate(cfg.stages):
         state = states[si]
-        n = xyz.shape[0]
+        row = dict(xyz=xyz, offset=offset, q=state.q.detach().cpu().numpy(), k=state.k.detach().cpu().numpy(), v=state.v.detach().cpu().numpy(),
+                   tables=[t.detach().cpu().numpy() for t in state.tables], go=state.grad_out.cpu().numpy())
+        host.append(row)
+        if si < len(cfg.stages) - 1:
+            n_offset = np.asarray(index_ref.transition_down_offset(offset, cfg.ratio), np.int32)
+            idx = ref.furthestsampling(xyz, offset, n_offset)
+            xyz, offset = np.ascontiguousarray(xyz[idx]), n_offset
+
+    def stage_seconds(si):
+        """everything the unit does at stage si: stratified FPS, both index patterns, depth x block fwd+bwd, TransitionDown FPS + kNN16, Upsample kNN3"""
+        st, hs = cfg.stages[si], host[si]
+        xyz, offset = hs["xyz"], hs["offset"]
         t0 = time.perf_counter()
         new_offset = index_ref.stratified_new_offset(offset, cfg.downsample_scale)
         ds = ref.furthestsampling(xyz, offset, new_offset)
         x_t = torch.from_numpy(xyz)
         blocks = [index_ref.build_stage_indices(x_t, offset, st.window_size, st.quant_size, torch.from_numpy(ds), par, "cuda") for par in (0, 1)]
-        t_total += time.perf_counter() - t0
-        parity[f"stage{si}/fps_stratified"] = bool(np.array_equal(ds, r["downsample_idx"].cpu().numpy()))
-        for par, name in ((0, "even"), (1, "odd")):
-            g = r[name]
-            parity[f"stage{si}/{name}/index_1"] = bool(np.array_equal(blocks[par]["index_1"].numpy(), g.index_1.cpu().numpy()))
-            parity[f"stage{si}/{name}/offsets"] = bool(np.array_equal(blocks[par]["offsets"].numpy(), g.offsets.cpu().numpy()))
-            parity[f"stage{si}/{name}/rel_idx"] = bool(np.array_equal(blocks[par]["rel_idx"].numpy(), g.rel_idx.cpu().numpy()))
-        q, k, v = (t.detach().cpu().numpy() for t in (state.q, state.k, state.v))
-        tq, tk, tv = (t.detach().cpu().numpy() for t in state.tables)
-        go = state.grad_out.cpu().numpy()
+        q, k, v, go = hs["q"], hs["k"], hs["v"], hs["go"]
+        tq, tk, tv = hs["tables"]
         L = tq.shape[0]
-        t0 = time.perf_counter()
         for b in range(st.depth):
             blk = blocks[b % 2]
             i1, offs = blk["index_1"].numpy().astype(np.int32), blk["offsets"].numpy().astype(np.int32)
             rel = np.clip(blk["rel_idx"].numpy(), 0, L - 1).astype(np.int32)
             a1 = ref.attention_step1_v2(q, k, i1, offs)
             a2 = ref.dot_prod_with_idx_v3(q, offs, k, i1, tq, tk, rel)
-            s = a1 + a2
-            sm = ref.segment_softmax(s, offs)
-            out = ref.attention_step2_with_rel_pos_value_v2(sm, v, offs, i1, tv, rel)
+            sm = ref.segment_softmax(a1 + a2, offs)
+            ref.attention_step2_with_rel_pos_value_v2(sm, v, offs, i1, tv, rel)
             ga, gv, gt = ref.attention_step2_with_rel_pos_value_v2_backward(go, sm, v, offs, i1, tv, rel)
             gs = ref.segment_softmax_backward(sm, ga, offs)
             ref.attention_step1_v2_backward(gs, q, k, i1, offs)
             ref.dot_prod_with_idx_v3_backward(gs, q, offs, k, i1, tq, tk, rel)
-        t_total += time.perf_counter() - t0
-        if st.depth % 2 == 0:
-            pass
-        last = r["out"].detach().cpu().numpy()
-        parity[f"stage{si}/attention_out_max_abs_err"] = float(np.abs(last - out).max())
         if si < len(cfg.stages) - 1:
-            t0 = time.perf_counter()
-            n_offset = index_ref.transition_down_offset(offset, cfg.ratio)
+            n_offset = np.asarray(index_ref.transition_down_offset(offset, cfg.ratio), np.int32)
             idx = ref.furthestsampling(xyz, offset, n_offset)
             n_xyz = np.ascontiguousarray(xyz[idx])
-            kidx, _ = ref.knnquery(cfg.k, xyz, n_xyz, offset, n_offset)
+            ref.knnquery(cfg.k, xyz, n_xyz, offset, n_offset)
             ref.knnquery(cfg.up_k, n_xyz, xyz, n_offset, offset)  # the Upsample kNN between the two stages
-            t_total += time.perf_counter() - t0
-            parity[f"stage{si}/transition_knn"] = bool(np.array_equal(kidx, r["transition_knn"].cpu().numpy()))
-            xyz, offset = n_xyz, n_offset
-    ok = all(v for k_, v in parity.items() if isinstance(v, bool)) and all(v < 1e-3 for v in parity.values() if isinstance(v, float))
-    return dict(value=round(N_POINTS / t_total, 1), unit="points/s", cores=cores, kind="port",
-                sample="1 full step (all 4 stages of the same 100k-point scene, every op incl. index build), 1 repetition, %.1f s" % t_total,
-                seconds=round(t_total, 2)), dict(all_ok=ok, checks=parity)
+        return time.perf_counter() - t0
+
+    def step_seconds(stages):
+        return sum(stage_seconds(si) for si in stages)
+
+    full = range(len(cfg.stages))
+    for _ in range(2):
+        step_seconds(full)
+    times = sorted(step_seconds(full) for _ in range(5))
+    med = times[2]
+    # 1-thread figure on a sub-sample: stages 2 and 3 of the same step, all-core time of the same sub-sample beside it
+    sub = (2, 3)
+    sub_all = sorted(step_seconds(sub) for _ in range(3))[1]
+    ref.set_num_threads(1)
+    sub_one = step_seconds(sub)
+    ref.set_num_threads(cores)
+    return dict(value=round(N_POINTS / med, 1), unit="points/s", cores=cores, kind="port",
+                sample="the full step (all 4 stages of the same 100k-point scene, every op incl. index build and FPS): 2 warm-ups, median of 5 "
+                       "repetitions on %d OpenMP threads; times %s s" % (cores, [round(t, 2) for t in times]),
+                seconds=round(med, 2),
+                one_thread=dict(sample="stages 2 and 3 of the same step (%d + %d points)" % (host[2]["xyz"].shape[0], host[3]["xyz"].shape[0]),
+                                seconds_1_thread=round(sub_one, 2), seconds_all_cores=round(sub_all, 2), thread_scaling=round(sub_one / sub_all, 2)))
 
 
 def main():
@@ -279,57 +313,72 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fused", action="store_true", help="skip the fused-module leg (counter passes)")
-    ap.add_argument("--in-flight", type=int, default=0,
-                    help="batches in flight (lanes); 1 = one batch at a time; 0 = by the length of the run: a deeper pipeline "
-                         "has a higher steady-state rate (24 steps: 24.0 / 23.0 / 21.8 ms per step with 3 / 4 / 5 lanes) but the "
-                         "timed region starts with an empty one, and filling it costs more (5 steps: 24.7 / 25.7 / 26.9 ms)")
+    ap.add_argument("--in-flight", type=int, default=IN_FLIGHT_DEFAULT, help="batches in flight of the in_flight leg (fixed; 1 = skip the leg)")
+    ap.add_argument("--shard", action="store_true", help="N > 1: ONE scene sharded over the ranks (SURVEY 8e) instead of one scene per rank")
     args = ap.parse_args()
-    if args.in_flight <= 0:
-        args.in_flight = 3 if args.steps < 8 else 4 if args.steps < 16 else 5
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))  # no GPU call has been made in this process
+    world = int(env_world or 1)
     rank = int(os.environ.get("RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    import torch
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL; BENCH_DIST_BACKEND=gloo only to rehearse the N>1 code path with several ranks on one GPU
         torch.distributed.init_process_group(os.environ.get("BENCH_DIST_BACKEND", "nccl"))
+        if torch.distributed.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: fewer ranks joined than --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     run = run_gpu(args, rank, world)
     if rank == 0:
-        ms_per_step = run["elapsed"] / args.steps * 1e3
-        comp = component_table(run["timer"], args.steps)
-        for name, row in component_table(run["live"], args.steps).items():
-            comp[name] = row  # the sampler ops: as measured inside the timed region
+        K = args.steps
+        sharded = bool(args.shard and world > 1)
+        scenes = 1 if sharded else world
+
+        def leg(seconds):
+            ms = seconds / K * 1e3
+            return dict(ms_per_step=round(ms, 3), value=round(N_POINTS * scenes / (ms / 1e3), 1))
+
+        cell, ops = leg(run["single_cell"]["elapsed"]), leg(run["single_ops"]["elapsed"])
+        comp = component_table(run["timer"], K)
         line = {
             "metric": "points/sec through StratifiedAttention fwd+bwd, 100k-pt scene",
-            "value": round(N_POINTS * world / (ms_per_step / 1e3), 1), "unit": "points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "one synthetic S3DIS-like room of 100000 points per GPU (BASELINE config 3: fwd+bwd), "
+            "value": cell["value"], "unit": "points/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": cell["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "one synthetic S3DIS-like room of 100000 points %s (BASELINE config 3, fp32: fwd+bwd), "
                                    "s3dis_stratified_transformer.yaml stages w=[.16,.32,.64,1.28] C=[48,96,192,384] h=[3,6,12,24] depths=[2,2,6,2]; "
-                                   "unit = index build + FPS + depth x (A1,A2,add,A3,A4 fwd+bwd) + TransitionDown FPS/kNN16 + Upsample kNN3 per stage",
-                       "points_per_gpu": N_POINTS, "pairs_stage0": run["results"][0]["M_even"],
-                       "stage_points": [r["n"] for r in run["results"]], "parallelism": "1 scene per rank, no data-path collective"},
-            "overlap": "within a batch: sampling chain, kNN and the next stage's index build on side streams beside the attention blocks; across batches: the sampling chains of the next batches_in_flight-1 batches are queued ahead (data-side prefetch), forward+backward of consecutive batches strictly in order; components_ms_per_step are per-op device times (fps/*: events inside the timed region; the others: single passes repeated with events around every op) and overlap in wall time",
-            "batches_in_flight": args.in_flight,
-            "same_results_as_single_pass": run["inflight_same"],
-            "single_batch": {"ms_per_step": round(run["single_elapsed"] / args.steps * 1e3, 3),
-                             "value": round(N_POINTS * world / (run["single_elapsed"] / args.steps), 1),
-                             "note": "the same K passes one batch at a time on the default stream (latency of a pass on its own) in this process, i.e. with GPU_MAX_HW_QUEUES=%s; with the runtime's default of 4 hardware queues a pass on its own takes ~38 ms (profiles/)" % os.environ.get("GPU_MAX_HW_QUEUES", "default")},
-            "fused_module": None if run["fused_elapsed"] is None else {"ms_per_step": round(run["fused_elapsed"] / args.steps * 1e3, 3),
-                             "note": "same timed loop with stratified_transformer_amd.fused.window_attention (fused logits+softmax forward, two-walk backward, one autograd node) instead of the five operators; not the headline"},
-            "roofline": roofline(comp, run),
-            "roofline_attention": roofline(comp, run, among="attn"),
+                                   "unit = index build + FPS + depth x attention block fwd+bwd + TransitionDown FPS/kNN16 + Upsample kNN3 per stage; "
+                                   "value = single_pass.%s" % ("sharded over the ranks" if sharded else "per GPU", "operator_api (sharded)" if sharded else "cell"),
+                       "points_per_scene": N_POINTS, "stages": step_attention_bytes(run["cfg"], run["results"])[1],
+                       "parallelism": ("1 scene over %d ranks: queries sharded by pair count, all-gather k/v, reduce-scatter dk/dv, all-reduce table grads" % world)
+                       if sharded else "1 scene per rank, no data-path collective"},
+            "single_pass": {"cell": cell, "operator_api": ops,
+                            "note": "K passes, each complete before the next starts; cell: attention blocks through fused.cell_attention "
+                                    "(window-centric kernels); operator_api: through the reference's five operators (what the unmodified model file calls)"},
+            "roofline": attention_roofline(run["single_cell"], run, K, "cell"),
+            "roofline_operator_api": attention_roofline(run["single_ops"], run, K, "operator_api"),
+            "fps": fps_report(run["single_cell"], run, K),
             "components_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(comp.items())},
+            "components_note": "per-op device times of passes repeated with events around every op (cell attention); chains overlap in wall time",
         }
+        if "inflight_cell" in run:
+            line["in_flight"] = {"batches_in_flight": args.in_flight, "cell": leg(run["inflight_cell"]), "operator_api": leg(run["inflight_ops"]),
+                                 "same_results_as_single_pass": run["inflight_same"],
+                                 "note": "the same K passes with the sampling chains (FPS, kNN: functions of the coordinates alone) of the next batches "
+                                         "queued ahead, forward+backward of consecutive batches strictly in order; a throughput configuration for a "
+                                         "training loop that owns its data-side prefetch, not reachable by the unmodified model file; GPU_MAX_HW_QUEUES=%s"
+                                         % os.environ.get("GPU_MAX_HW_QUEUES", "default")}
+        if sharded:
+            live = component_table(run["single_cell"]["live"], K)
+            line["collective_ms"] = round(sum(v["ms_per_step"] for k, v in live.items() if k.startswith("comm/")), 3)
         if world == 1 and not args.no_cpu_baseline:
-            base, parity = cpu_baseline(run)
+            base = cpu_baseline(run)
             line["cpu_baseline"] = base
             line["gpu_over_cpu"] = round(line["value"] / base["value"], 2)
-            line["parity_at_full_size"] = parity["all_ok"]
-            if not parity["all_ok"]:
-                line["parity_failures"] = {k: v for k, v in parity["checks"].items() if v is False or (isinstance(v, float) and v >= 1e-3)}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -43,6 +43,7 @@ class BlockIndex:
     rel_idx: torch.Tensor          # [M,3] i32
     n_dense: torch.Tensor          # [N] i64 dense keys per query (diagnostics)
     cells: object = None           # CellPlan of the same pattern (stage_index_hip(..., cell_table_rows=L)), else None
+    shard: object = None           # (QueryShard, bounds, (rank, world)) cached by pipeline.attention_block for a sharded scene
 
 
 def batch_ids(offset, n):

@@ -114,14 +114,31 @@ def make_stage_state(xyz, offset, st, seed):
                       torch.randn(n, h, d, generator=g, device=xyz.device))
 
 
-def attention_block(state, blk, timer, fused=False):
+def attention_block(state, blk, timer, fused=False, shard=None):
     """WindowAttention.forward's op sequence (model/stratified_transformer.py:183-208) + its backward.
     fused=True: the optional one-function fast path (fused.window_attention) instead of the five
-    operators; same numbers."""
+    operators; fused="cell": the window-centric kernels (fused.cell_attention); same numbers.
+    shard=(rank, world): this rank's query range of the block only (sharding.py): k / v rows all-gathered,
+    their gradients reduce-scattered, table gradients all-reduced; returns the rank's rows of the output."""
     q, k, v = state.q, state.k, state.v
     tq, tk, tv = state.tables
     for t in (q, k, v, tq, tk, tv):
         t.grad = None
+    if shard is not None:
+        from . import sharding
+        rank, world = shard
+        if getattr(blk, "shard", None) is None or blk.shard[2] != (rank, world):
+            sh, bounds = sharding.make_shard(blk, rank, world)
+            blk.shard = (sh, bounds, (rank, world))
+        sh, bounds, _ = blk.shard
+        sharding.set_timer(timer)
+        try:
+            out = timer.run("attn_fwd/sharded", sharding.sharded_window_attention, P, sh, bounds, rank, q[sh.lo:sh.hi], k[sh.lo:sh.hi], v[sh.lo:sh.hi],
+                            tq, tk, tv, blk.n_max)
+            timer.run("attn_bwd", out.backward, state.grad_out[sh.lo:sh.hi])
+        finally:
+            sharding.set_timer(None)
+        return out
     if fused == "cell":
         from . import fused as F
         out = timer.run("attn_fwd/cell", F.cell_attention, q, k, v, tq, tk, tv, blk.cells)
@@ -161,9 +178,9 @@ def geometry_stream(device, which=0):
     return _GEO_STREAMS[key]
 
 
-def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0, cells=False):
+def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0, cells=False, shard=None):
     """Runs the whole unit once (both phases of scene_pass_phases back to back).  Returns (states, results)."""
-    gen = scene_pass_phases(xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane, cells=cells)
+    gen = scene_pass_phases(xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane, cells=cells, shard=shard)
     next(gen)
     try:
         next(gen)
@@ -173,7 +190,7 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
 
 
 def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0,
-                      inputs_resident=False, offset_host=None, cells=False):
+                      inputs_resident=False, offset_host=None, cells=False, shard=None):
     """Generator form of scene_pass: the first next() enqueues the geometry chain of ALL stages (no host sync in
     it) and yields; the second runs the index builds (which stop the host: key width, pair count) and the attention
     blocks, and returns (states, results) through StopIteration.  passes_in_flight puts the first phase of the next
@@ -298,7 +315,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         with torch.cuda.stream(idx_s):
             if use_hip_index:
                 even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds,
-                                         table_rows(st) if (cells or fused == "cell") else None,
+                                         table_rows(st) if (cells or (fused == "cell" and not shard)) else None,
                                          index_build.cell_query_cap(x.shape[0], st.num_heads))
             else:
                 parts = timer.run("index/partition", index_build.stage_partitions, x, off, st.window_size)
@@ -343,11 +360,14 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         # short enough for the launches to fall behind otherwise)
         early = si + 1 in stages and si > first
         for b in range(st.depth):
-            out = attention_block(state, even if b % 2 == 0 else odd, timer, fused)
+            out = attention_block(state, even if b % 2 == 0 else odd, timer, False if shard else fused, shard)
             if early and b == 0:
                 index(si + 1)
         results.append(dict(stage=si, n=x.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),
                             even=even, odd=odd, downsample_idx=ds, out=out))
+        if shard is not None:  # `out` holds the rank's rows of the last block only
+            last_blk = even if (st.depth - 1) % 2 == 0 else odd
+            results[-1]["out_rows"] = (last_blk.shard[0].lo, last_blk.shard[0].hi)
         if knn_idx is not None:
             results[-1]["transition_knn"] = knn_idx
         if si + 1 in stages and not early:

@@ -23,6 +23,21 @@ import torch
 import torch.distributed as dist
 
 
+_TIMER = None
+
+
+def set_timer(timer):
+    """pipeline.Timer (or None): the collectives below are then recorded as comm/* spans on the current stream"""
+    global _TIMER
+    _TIMER = timer
+
+
+def _comm(name, fn, *a, **k):
+    if _TIMER is None:
+        return fn(*a, **k)
+    return _TIMER.run("comm/" + name, fn, *a, **k)
+
+
 @dataclass
 class QueryShard:
     lo: int                    # first owned query
@@ -53,6 +68,22 @@ def make_shard(block, rank, world, bounds=None):
                       block.index_1[p0:p1].contiguous(), block.rel_idx[p0:p1].contiguous(), p0, p1), bounds
 
 
+def _host_staged(group):
+    """gloo moves host memory: device tensors are staged through the host (tests / rehearsals on one GPU; the product
+    backend is "nccl" = RCCL, which takes device tensors directly)"""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(t, group):
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        _comm("all_reduce", dist.all_reduce, h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        _comm("all_reduce", dist.all_reduce, t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 class _GatherRows(torch.autograd.Function):
     """forward: all-gather row shards (padded to the longest shard, so every backend's fixed-size
     collective applies) into the full [N, ...] tensor; backward: reduce-scatter of the full gradient back
@@ -65,28 +96,29 @@ class _GatherRows(torch.autograd.Function):
         sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
         mx = max(sizes)
         tail = tuple(local.shape[1:])
-        padded = torch.zeros((mx,) + tail, dtype=local.dtype, device=local.device)
+        staged = local.is_cuda and _host_staged(group)
+        dev = torch.device("cpu") if staged else local.device
+        padded = torch.zeros((mx,) + tail, dtype=local.dtype, device=dev)
         padded[: sizes[rank]] = local
-        gathered = torch.empty((world, mx) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(gathered.view((world * mx,) + tail), padded, group=group)
-        return torch.cat([gathered[r, : sizes[r]] for r in range(world)], 0)
+        gathered = torch.empty((world, mx) + tail, dtype=local.dtype, device=dev)
+        _comm("all_gather", dist.all_gather_into_tensor, gathered.view((world * mx,) + tail), padded, group=group)
+        return torch.cat([gathered[r, : sizes[r]] for r in range(world)], 0).to(local.device)
 
     @staticmethod
     def backward(ctx, grad_full):
         bounds, rank, group = ctx.bounds, ctx.rank, ctx.group
         world = len(bounds) - 1
         sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
-        if grad_full.is_cuda:
+        if grad_full.is_cuda and not _host_staged(group):
             mx = max(sizes)
             tail = tuple(grad_full.shape[1:])
             padded = torch.zeros((world, mx) + tail, dtype=grad_full.dtype, device=grad_full.device)
             for r in range(world):
                 padded[r, : sizes[r]] = grad_full[bounds[r]:bounds[r + 1]]
             out = torch.empty((mx,) + tail, dtype=grad_full.dtype, device=grad_full.device)
-            dist.reduce_scatter_tensor(out, padded.view((world * mx,) + tail), op=dist.ReduceOp.SUM, group=group)
+            _comm("reduce_scatter", dist.reduce_scatter_tensor, out, padded.view((world * mx,) + tail), op=dist.ReduceOp.SUM, group=group)
             return out[: sizes[rank]].contiguous(), None, None, None
-        g = grad_full.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        g = _all_reduce_sum(grad_full.contiguous().clone(), group)
         return g[bounds[rank]:bounds[rank + 1]].contiguous(), None, None, None
 
 
@@ -100,9 +132,7 @@ class _SharedParam(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g, None
+        return _all_reduce_sum(g.contiguous().clone(), ctx.group), None
 
 
 def sharded_window_attention(ops, shard, bounds, rank, q_local, k_local, v_local, table_q, table_k, table_v, n_max=0,

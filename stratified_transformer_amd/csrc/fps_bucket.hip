@@ -23,7 +23,7 @@
 //   ~m * 3 workgroup barriers instead of m full-cloud scans.
 //
 // One workgroup per batch element (as the reference): no cross-workgroup synchronisation at all.
-#include "common.h"
+#include "fps_common.h"
 #include <hipcub/hipcub.hpp>
 #include <cstdio>
 #include <cstdlib>
@@ -37,9 +37,6 @@ Workspace &workspace() {
 
 constexpr int FPS_MAX_BUCKETS = 2048;
 
-__device__ __forceinline__ float sqd(float dx, float dy, float dz) {
-    return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-}
 // maximum over lanes 0..15 only (values in the first row): four row steps, result in every lane of row 0
 __device__ __forceinline__ unsigned row0_max_u32(unsigned v) {
     v = dpp_step<0xB1, 0xF>(v);
@@ -54,18 +51,6 @@ __device__ __forceinline__ unsigned long long wmax64(unsigned long long v) {
     const unsigned mh = wave_max_u32(hi);
     const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
     return ((unsigned long long)mh << 32) | ml;
-}
-__device__ __forceinline__ unsigned long long key_of(float d2, int rel, int Bref, int log2B) {
-    const unsigned tref = (unsigned)rel & (unsigned)(Bref - 1);
-    const unsigned cidx = (unsigned)rel >> log2B;
-    const unsigned brev = log2B ? (__brev(tref) >> (32 - log2B)) : 0u;
-    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(0x7fffffffu - ((brev << 21) | cidx));
-}
-__device__ __forceinline__ int rel_of(unsigned long long key, int Bref, int log2B) {
-    const unsigned key2 = 0x7fffffffu - (unsigned)(key & 0xffffffffull);
-    const unsigned brev = key2 >> 21, cidx = key2 & ((1u << 21) - 1);
-    const unsigned tref = log2B ? (__brev(brev) >> (32 - log2B)) : 0u;
-    return (int)(cidx * (unsigned)Bref + tref);
 }
 
 // ---- set-up ----------------------------------------------------------------------------------
@@ -286,27 +271,6 @@ __global__ __launch_bounds__(VER_T) void fps_rebuild_kernel(const float *__restr
 // prev_idx/prev_offset (optional): samples already computed on this workspace by an earlier call for the
 // same cloud (FPS is deterministic: a shorter request is a prefix of a longer one) — copied, then resumed.
 
-struct KeyMax {
-    unsigned long long key;  // wave maximum
-    int lane;                // a lane holding it (unique when keys are unique)
-};
-// 64-bit wave max: DPP max of the high words; the low words only need a second pass when several lanes
-// share the maximal high word (exact distance ties).
-__device__ __forceinline__ KeyMax wave_key_max(unsigned long long v) {
-    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
-    const unsigned mh = wave_max_u32(hi);
-    const unsigned long long tied = __ballot(hi == mh);
-    KeyMax r;
-    if (__popcll(tied) == 1) {
-        r.lane = __ffsll(tied) - 1;
-        r.key = ((unsigned long long)mh << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, r.lane);
-    } else {
-        const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
-        r.key = ((unsigned long long)mh << 32) | ml;
-        r.lane = __ffsll((unsigned long long)__ballot(hi == mh && lo == ml)) - 1;
-    }
-    return r;
-}
 
 __device__ __forceinline__ void lds_barrier() {
     // LDS traffic of this wave retired, then the workgroup barrier; global stores stay in flight
@@ -316,9 +280,6 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float rl(float v, int lane) {  // value of a wave-uniform lane, no LDS round trip
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
 // branch-free variant (two DPP passes), so that several independent reductions can be interleaved
 __device__ __forceinline__ KeyMax wave_key_max_bf(unsigned long long v) {
     const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
@@ -761,6 +722,12 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     }
     const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);
     const int nbuckets = div_up(n, BSZ);
+    // round-based sampler (fps_lazy.hip) on the same state; P2_FPS_STEPWISE=1 keeps the step-by-step kernel below
+    static const bool stepwise = getenv("P2_FPS_STEPWISE") != nullptr;
+    if (BSZ == 64 && !stepwise) {
+        fps_lazy_launch(b, Bref, log2B, xyz, offset, new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, st);
+        return true;
+    }
     static const int nw_env = getenv("P2_FPS_WAVES") ? atoi(getenv("P2_FPS_WAVES")) : 0;
     const int NWsel = nw_env == 8 ? 8 : 16;
     const int per_lane = div_up(nbuckets, NWsel * 64);

@@ -1,0 +1,469 @@
+// I1 (fast path, second generation): exact furthest point sampling in ROUNDS, gfx950.
+//
+// FPS is m dependent arg-max steps, and fps_bucket.hip pays ~1 us of one CU's latency for each of them.  But the
+// steps are almost independent: a step only changes the running min-distance of the points NEAR its sample, and the
+// points with the largest min-distances are spread over the whole cloud.  A round therefore decides MANY steps at once:
+//
+//   candidates  S = every point whose key (min-dist bits << 32 | tie rank) is >= a threshold tau; all other points
+//               have keys < tau, now and - keys only decrease - for the rest of the round;
+//   resolve     in key order (the order the reference would select them) a candidate j is the reference's next sample
+//               iff no ALREADY ACCEPTED candidate i (key_i > key_j) lies closer to it than its min-distance
+//               (d(i, j) < d_j: its key would have dropped first).  With the pairwise predicate
+//               hit[j][i] = key_i > key_j && d(i, j) < d_j the accepted set is the unique fixed point of
+//               acc_j = !exists i: hit[j][i] && acc_i  (a chain of dependencies along the key order; interactions are
+//               rare, the iteration settles in a few sweeps).  A dropped candidate's new key is bounded by its
+//               distance to the accepted candidates that hit it; nothing below the largest such bound (or below a
+//               candidate that did not fit the list) is accepted in this round - it waits for the next one;
+//   update      the accepted samples are applied to the cloud together: min-dist = min over the new samples, bucket by
+//               bucket as in fps_bucket.hip (points Morton-sorted in buckets of 64 with boxes; a bucket is skipped when
+//               no accepted sample can reach it), with a two-level box test (16-bucket super-buckets first).
+// The index sequence is the reference's, bit for bit (same fma chain, same tie ranks, min() is order-independent);
+// ~100 rounds replace 25 000 dependent steps.  A round that accepts nothing (possible only when the candidate list
+// overflowed) falls back to ONE literal step from the bucket maxima, so progress is unconditional.
+//
+// One workgroup of 16 waves per batch element; state (pts.w = running min-dist, tie ranks, Morton order) and the
+// resume / verified-prefix conventions are fps_bucket.hip's.
+#include "fps_common.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace p2 {
+
+constexpr int LZ_NW = 16;
+constexpr int LZ_NT = LZ_NW * 64;
+constexpr int LZ_NBL = 2;                // owned buckets per lane: up to 2 * 64 * 16 = 2048 buckets of 64 points
+constexpr int LZ_CAP = 512;              // candidates / accepted samples per round
+constexpr int LZ_WORDS = LZ_CAP / 32;
+constexpr int LZ_TARGET = 352;           // candidates the threshold controller aims at
+constexpr int LZ_MAXSB = LZ_NBL * 64;    // super-buckets: the 16 buckets (one per wave) with the same (slot, lane)
+
+__device__ __forceinline__ unsigned ord_bits(float v) {  // order-preserving float -> unsigned
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_float(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+// lower bound of the squared distance from a point to a box: same fma chain as sqd on clamped differences, every
+// rounding monotone, so lb <= d(point, p) in fp32 for every p inside the box (fps_bucket.hip)
+__device__ __forceinline__ float box_lb(float x, float y, float z, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+    const float dx = fmaxf(fmaxf(mnx - x, x - mxx), 0.f);
+    const float dy = fmaxf(fmaxf(mny - y, y - mxy), 0.f);
+    const float dz = fmaxf(fmaxf(mnz - z, z - mxz), 0.f);
+    return sqd(dx, dy, dz);
+}
+
+// STAMP: diagnostic build only (P2_FPS_STAMPS=1): cycle sums of the phases of wave 0 and round statistics -> dbg
+template <bool STAMP>
+__global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                                         const int *__restrict__ new_offset, float4 *__restrict__ pts,
+                                                         const unsigned *__restrict__ rank, const int *__restrict__ prev_idx,
+                                                         const int *__restrict__ prev_offset, const int *__restrict__ verified,
+                                                         int *__restrict__ idx, unsigned long long *__restrict__ dbg = nullptr) {
+    unsigned long long c_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+    auto stamp = [&](int ph) {
+        if (STAMP) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            c_ph[ph] += t - t_last;
+            t_last = t;
+        }
+    };
+    if (STAMP) t_last = __builtin_amdgcn_s_memtime();
+    constexpr int NW = LZ_NW, NT = LZ_NT, NBL = LZ_NBL, CAP = LZ_CAP, WORDS = LZ_WORDS;
+    __shared__ float cx[CAP], cy[CAP], cz[CAP], cd[CAP];  // candidates
+    __shared__ unsigned clo[CAP];
+    __shared__ unsigned hit[CAP][WORDS];
+    __shared__ int gtc[CAP];                                // candidates with a larger key
+    __shared__ unsigned short dlist[CAP];                   // dropped candidates
+    __shared__ float ax[CAP], ay[CAP], az[CAP];            // accepted samples, in selection order
+    __shared__ unsigned sbhit[LZ_MAXSB][WORDS];            // accepted samples that may reach a super-bucket
+    __shared__ unsigned sbmax[2][LZ_MAXSB];                // largest min-dist (bits) inside a super-bucket, double-buffered
+    __shared__ unsigned sbbox[LZ_MAXSB][6];                // super-bucket boxes (ord_bits)
+    __shared__ unsigned accw[2][WORDS];
+    __shared__ unsigned long long wkey[NW];
+    __shared__ unsigned long long s_tover, s_tdrop;
+    __shared__ int s_cnt, s_nd, s_nacc, s_changed[2];
+
+    const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
+    const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
+    if (end_n <= start_n) {
+        for (int j = start_m + tid; j < end_m; j += NT) idx[j] = start_n;
+        return;
+    }
+    const int n = end_n - start_n, m = end_m - start_m;
+    const int nb = (n + 63) / 64;
+    const int nsb = (nb + NW - 1) / NW;  // super-buckets in use (<= LZ_MAXSB)
+
+    // samples inherited from the previous call on this state, or verified to be the identity prefix (fps_bucket.hip)
+    int done = 0;
+    if (prev_idx) {
+        const int ps = bid == 0 ? 0 : prev_offset[bid - 1], pe = prev_offset[bid];
+        done = min(pe - ps, m);
+        for (int t = tid; t < done; t += NT) idx[start_m + t] = prev_idx[ps + t];
+    }
+    if (verified) {
+        const int v = min(verified[bid], m);
+        if (v > done) {
+            for (int t = tid; t < v; t += NT) idx[start_m + t] = start_n + t;
+            done = v;
+        }
+    }
+    if (done >= m) return;
+
+    // ---- owned buckets: slot s of lane l  <->  bucket (s*64 + l)*NW + wave; box and largest key in registers ----
+    float mnx[NBL], mny[NBL], mnz[NBL], mxx[NBL], mxy[NBL], mxz[NBL];
+    unsigned long long key[NBL];
+#pragma unroll
+    for (int s = 0; s < NBL; s++) {
+        mnx[s] = mny[s] = mnz[s] = INFINITY;  // an absent bucket is never reached and never holds a candidate
+        mxx[s] = mxy[s] = mxz[s] = -INFINITY;
+        key[s] = 0ull;
+    }
+    for (int t = tid; t < LZ_MAXSB; t += NT) {
+        sbbox[t][0] = sbbox[t][1] = sbbox[t][2] = 0xffffffffu;
+        sbbox[t][3] = sbbox[t][4] = sbbox[t][5] = 0u;
+        sbmax[0][t] = sbmax[1][t] = 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NBL; s++) {
+        for (int l = 0; l < 64; l++) {
+            const int bk = (s * 64 + l) * NW + wave;
+            if (bk >= nb) break;
+            const int pos = min(start_n + bk * 64 + lane, end_n - 1);
+            const float4 p = pts[pos];
+            float a0 = p.x, a1 = p.y, a2 = p.z, b0 = p.x, b1 = p.y, b2 = p.z;
+            for (int st = 1; st < 64; st <<= 1) {
+                a0 = fminf(a0, __shfl_xor(a0, st, 64)); a1 = fminf(a1, __shfl_xor(a1, st, 64)); a2 = fminf(a2, __shfl_xor(a2, st, 64));
+                b0 = fmaxf(b0, __shfl_xor(b0, st, 64)); b1 = fmaxf(b1, __shfl_xor(b1, st, 64)); b2 = fmaxf(b2, __shfl_xor(b2, st, 64));
+            }
+            const KeyMax km = wave_key_max(((unsigned long long)__float_as_uint(p.w) << 32) | rank[pos]);
+            if (lane == l) {
+                mnx[s] = a0; mny[s] = a1; mnz[s] = a2; mxx[s] = b0; mxy[s] = b1; mxz[s] = b2;
+                key[s] = km.key;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NBL; s++)
+        if (key[s] != 0ull || mnx[s] != INFINITY) {
+            const int sb = s * 64 + lane;
+            atomicMin(&sbbox[sb][0], ord_bits(mnx[s])); atomicMin(&sbbox[sb][1], ord_bits(mny[s])); atomicMin(&sbbox[sb][2], ord_bits(mnz[s]));
+            atomicMax(&sbbox[sb][3], ord_bits(mxx[s])); atomicMax(&sbbox[sb][4], ord_bits(mxy[s])); atomicMax(&sbbox[sb][5], ord_bits(mxz[s]));
+            atomicMax(&sbmax[0][sb], (unsigned)(key[s] >> 32));
+        }
+    if (tid == 0 && done == 0) idx[start_m] = start_n;
+    __syncthreads();  // boxes complete; the idx[] copies above are ordered before the read below
+    // the last selected sample has not been applied to the min-dist field yet (fps_bucket.hip's convention; applying a
+    // sample twice is harmless): it is the first round's accepted set
+    {
+        const int first = done == 0 ? start_n : idx[start_m + done - 1];
+        if (tid == 0) {
+            ax[0] = xyz[(size_t)first * 3 + 0];
+            ay[0] = xyz[(size_t)first * 3 + 1];
+            az[0] = xyz[(size_t)first * 3 + 2];
+        }
+    }
+    done = max(done, 1);
+    int A = 1;                                   // accepted samples waiting to be applied
+    float frac = fminf(0.5f, 2.0f * LZ_TARGET / (float)n);  // threshold = top min-dist * (1 - frac)
+    int buf = 0;                                 // sbmax[buf] = current super-bucket maxima
+    __syncthreads();
+
+    stamp(0);  // 0: set-up
+    for (;;) {
+        // ================= update: apply the A accepted samples =================
+        const int nwA = (A + 31) >> 5;
+        if (STAMP) { c_ph[10] += 1; c_ph[11] += A; }
+        // (1) sample x super-bucket box tests -> sbhit; one (super-bucket, 32 samples) unit per thread trip
+        for (int u = tid; u < nsb * nwA; u += NT) {
+            const int sb = u / nwA, w = u - sb * nwA;
+            const float bx0 = ord_float(sbbox[sb][0]), by0 = ord_float(sbbox[sb][1]), bz0 = ord_float(sbbox[sb][2]);
+            const float bx1 = ord_float(sbbox[sb][3]), by1 = ord_float(sbbox[sb][4]), bz1 = ord_float(sbbox[sb][5]);
+            const float dmax = __uint_as_float(sbmax[buf][sb]);
+            unsigned bits = 0u;
+            const int a0 = w * 32, a1 = min(A, a0 + 32);
+            for (int a = a0; a < a1; a++)
+                if (box_lb(ax[a], ay[a], az[a], bx0, by0, bz0, bx1, by1, bz1) < dmax) bits |= 1u << (a - a0);
+            sbhit[sb][w] = bits;
+        }
+        for (int t = tid; t < LZ_MAXSB; t += NT) sbmax[buf ^ 1][t] = 0u;
+        __syncthreads();
+        stamp(1);  // 1: sample x super-bucket tests
+        // (2) every lane: which of those samples reach its own buckets (up to four ids kept; more: all of the super-bucket's)
+        unsigned long long lst[NBL];
+        int cntl[NBL];
+#pragma unroll
+        for (int s = 0; s < NBL; s++) {
+            lst[s] = 0ull;
+            cntl[s] = 0;
+            const int sb = s * 64 + lane;
+            if (sb < nsb && mnx[s] != INFINITY) {
+                const float dmax = __uint_as_float((unsigned)(key[s] >> 32));
+                for (int w = 0; w < nwA; w++) {
+                    unsigned bits = sbhit[sb][w];
+                    while (bits) {
+                        const int a = w * 32 + __ffs(bits) - 1;
+                        bits &= bits - 1;
+                        if (box_lb(ax[a], ay[a], az[a], mnx[s], mny[s], mnz[s], mxx[s], mxy[s], mxz[s]) < dmax) {
+                            if (cntl[s] < 4) lst[s] |= (unsigned long long)a << (16 * cntl[s]);
+                            cntl[s]++;
+                        }
+                    }
+                }
+            }
+        }
+        stamp(2);  // 2: own-bucket tests
+        // (3) the wave updates its touched buckets: 64 lanes <-> 64 points, the loads of up to four buckets in flight together
+#pragma unroll
+        for (int s = 0; s < NBL; s++) {
+            unsigned long long touched = __ballot(cntl[s] > 0);
+            while (touched) {
+                int ol[4], pos[4];
+                float4 p[4];
+                unsigned rk[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ol[u] = touched ? __ffsll(touched) - 1 : -1;  // wave-uniform
+                    touched &= touched - 1;                       // (0 & anything stays 0)
+                    pos[u] = min(start_n + ((s * 64 + max(ol[u], 0)) * NW + wave) * 64 + lane, end_n - 1);  // lanes past the end copy the last point
+                    if (ol[u] >= 0) { p[u] = pts[pos[u]]; rk[u] = rank[pos[u]]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (ol[u] < 0) continue;  // wave-uniform
+                    const int c = __builtin_amdgcn_readlane(cntl[s], ol[u]);
+                    const unsigned l0 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)lst[s], ol[u]);
+                    const unsigned l1 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(lst[s] >> 32), ol[u]);
+                    float d2 = p[u].w;
+                    if (c <= 4) {
+                        const unsigned long long ids = ((unsigned long long)l1 << 32) | l0;
+                        for (int v = 0; v < c; v++) {
+                            const int a = (int)((ids >> (16 * v)) & 0xffffu);
+                            d2 = fminf(d2, sqd(p[u].x - ax[a], p[u].y - ay[a], p[u].z - az[a]));
+                        }
+                    } else {
+                        const int sb = s * 64 + ol[u];
+                        for (int w = 0; w < nwA; w++) {
+                            unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane((int)sbhit[sb][w]);
+                            while (bits) {
+                                const int a = w * 32 + __ffs(bits) - 1;
+                                bits &= bits - 1;
+                                d2 = fminf(d2, sqd(p[u].x - ax[a], p[u].y - ay[a], p[u].z - az[a]));
+                            }
+                        }
+                    }
+                    reinterpret_cast<float *>(pts + pos[u])[3] = d2;
+                    const KeyMax km = wave_key_max(((unsigned long long)__float_as_uint(d2) << 32) | rk[u]);
+                    if (lane == ol[u]) key[s] = km.key;
+                }
+            }
+        }
+        stamp(3);  // 3: bucket updates
+        // ================= select =================
+        {
+            unsigned long long mk = key[0];
+#pragma unroll
+            for (int s = 1; s < NBL; s++) mk = key[s] > mk ? key[s] : mk;
+            const KeyMax wm = wave_key_max(mk);
+            if (lane == 0) wkey[wave] = wm.key;
+#pragma unroll
+            for (int s = 0; s < NBL; s++)
+                if (mnx[s] != INFINITY) atomicMax(&sbmax[buf ^ 1][s * 64 + lane], (unsigned)(key[s] >> 32));
+        }
+        buf ^= 1;
+        if (tid == 0) { s_cnt = 0; s_tover = 0ull; s_tdrop = 0ull; s_nd = 0; s_nacc = 0; s_changed[0] = 0; s_changed[1] = 0; }
+        for (int t = tid; t < CAP; t += NT) gtc[t] = 0;
+        __syncthreads();
+        stamp(4);  // 4: maxima + barrier (waiting for the slowest wave's updates)
+        if (done >= m) break;  // (uniform) everything selected, and applied
+        unsigned long long gtop = 0ull;
+        {
+            const unsigned long long v = lane < NW ? wkey[lane] : 0ull;
+            gtop = wave_key_max(v).key;
+        }
+        const float dtop = __uint_as_float((unsigned)(gtop >> 32));
+        // ---- gather the candidates: every point with min-dist >= tau (two tighter retries if the list overflows) ----
+        int K = 0;
+        for (int attempt = 0;; attempt++) {
+            const unsigned taub = __float_as_uint(fmaxf(dtop * (1.0f - frac), 0.f));
+#pragma unroll
+            for (int s = 0; s < NBL; s++) {
+                unsigned long long have = __ballot(mnx[s] != INFINITY && (unsigned)(key[s] >> 32) >= taub);
+                while (have) {
+                    int ol[4], pos[4];
+                    float4 p[4];
+                    unsigned rk[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        ol[u] = have ? __ffsll(have) - 1 : -1;
+                        have &= have - 1;
+                        pos[u] = start_n + ((s * 64 + max(ol[u], 0)) * NW + wave) * 64 + lane;
+                        if (ol[u] >= 0) { p[u] = pts[min(pos[u], end_n - 1)]; rk[u] = rank[min(pos[u], end_n - 1)]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (ol[u] < 0) continue;  // wave-uniform
+                        const bool cand = pos[u] < end_n && __float_as_uint(p[u].w) >= taub;
+                        const unsigned long long cm = __ballot(cand);
+                        if (cm) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(&s_cnt, __popcll(cm));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (cand) {
+                                const int at = base + __popcll(cm & ((1ull << lane) - 1ull));
+                                if (at < CAP) {
+                                    cx[at] = p[u].x; cy[at] = p[u].y; cz[at] = p[u].z; cd[at] = p[u].w; clo[at] = rk[u];
+                                } else {
+                                    atomicMax(&s_tover, ((unsigned long long)__float_as_uint(p[u].w) << 32) | rk[u]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const int found = s_cnt;
+            K = min(found, CAP);
+            // threshold controller (every thread computes the same): aim at LZ_TARGET candidates
+            const float ratio = fminf(fmaxf((float)LZ_TARGET / (float)max(found, 1), 0.5f), 2.0f);
+            if (found > CAP && attempt < 2 && frac > 1e-7f) {
+                frac *= 0.25f * (float)CAP / (float)found;
+                __syncthreads();  // everybody has read s_cnt
+                if (tid == 0) { s_cnt = 0; s_tover = 0ull; }
+                __syncthreads();
+                continue;
+            }
+            frac = fminf(fmaxf(frac * ratio, 1e-7f), 0.5f);
+            break;
+        }
+        stamp(5);  // 5: gather
+        const int nwK = (K + 31) >> 5;
+        const unsigned long long tover = s_tover;
+        // ---- pairwise: hit[j][i] = key_i > key_j && d(i, j) < d_j; gtc[j] = candidates with a larger key ----
+        for (int u = tid; u < K * nwK; u += NT) {
+            const int j = u / nwK, w = u - j * nwK;
+            const float xj = cx[j], yj = cy[j], zj = cz[j], dj = cd[j];
+            const unsigned hj = __float_as_uint(dj), lj = clo[j];
+            unsigned bits = 0u;
+            int gt = 0;
+            const int i0 = w * 32, i1 = min(K, i0 + 32);
+            for (int i = i0; i < i1; i++) {
+                const unsigned hi = __float_as_uint(cd[i]);
+                const bool before = hi > hj || (hi == hj && clo[i] > lj);
+                gt += before ? 1 : 0;
+                if (before && sqd(xj - cx[i], yj - cy[i], zj - cz[i]) < dj) bits |= 1u << (i - i0);
+            }
+            hit[j][w] = bits;
+            if (gt) atomicAdd(&gtc[j], gt);
+        }
+        if (tid < WORDS) {
+            const int lo = tid * 32;
+            accw[0][tid] = K >= lo + 32 ? 0xffffffffu : (K > lo ? ((1u << (K - lo)) - 1u) : 0u);
+        }
+        __syncthreads();
+        stamp(6);  // 6: pairwise
+        // ---- resolve: fixed point of acc_j = !exists i: hit[j][i] && acc_i ----
+        int cur = 0;
+        for (int it = 0; it < CAP; it++) {
+            bool mine = false, old = false;
+            if (tid < K) {
+                unsigned h = 0u;
+                for (int w = 0; w < nwK; w++) h |= hit[tid][w] & accw[cur][w];
+                mine = h == 0u;
+                old = (accw[cur][tid >> 5] >> (tid & 31)) & 1u;
+            }
+            const unsigned long long bm = __ballot(mine);
+            if (lane == 0 && wave * 2 < WORDS) {
+                accw[cur ^ 1][wave * 2] = (unsigned)bm;
+                accw[cur ^ 1][wave * 2 + 1] = (unsigned)(bm >> 32);
+            }
+            if (mine != old) s_changed[it & 1] = 1;
+            if (tid == 0) s_changed[(it + 1) & 1] = 0;
+            __syncthreads();
+            cur ^= 1;
+            if (!s_changed[it & 1]) break;  // uniform: read after the barrier, reset two iterations later
+        }
+        stamp(7);  // 7: fixed point
+        // ---- dropped candidates bound what may still be accepted ----
+        bool acc = false;
+        unsigned long long kj = 0ull;
+        if (tid < K) {
+            acc = (accw[cur][tid >> 5] >> (tid & 31)) & 1u;
+            kj = ((unsigned long long)__float_as_uint(cd[tid]) << 32) | clo[tid];
+            if (!acc) {
+                float nd = cd[tid];
+                for (int w = 0; w < nwK; w++) {
+                    unsigned bits = hit[tid][w] & accw[cur][w];
+                    while (bits) {
+                        const int i = w * 32 + __ffs(bits) - 1;
+                        bits &= bits - 1;
+                        nd = fminf(nd, sqd(cx[tid] - cx[i], cy[tid] - cy[i], cz[tid] - cz[i]));
+                    }
+                }
+                atomicMax(&s_tdrop, ((unsigned long long)__float_as_uint(nd) << 32) | clo[tid]);
+                dlist[atomicAdd(&s_nd, 1)] = (unsigned short)tid;
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned long long tcut = tover > s_tdrop ? tover : s_tdrop;
+            const int remaining = m - done;
+            bool fin = acc && kj > tcut;
+            int r = 0;
+            if (fin) {
+                r = gtc[tid];
+                const int nd_ = s_nd;
+                for (int t = 0; t < nd_; t++) {
+                    const int i = dlist[t];
+                    const unsigned long long ki = ((unsigned long long)__float_as_uint(cd[i]) << 32) | clo[i];
+                    r -= ki > kj ? 1 : 0;
+                }
+                fin = r < remaining;
+            }
+            if (fin) {
+                ax[r] = cx[tid]; ay[r] = cy[tid]; az[r] = cz[tid];
+                idx[start_m + done + r] = start_n + rel_of(kj, Bref, log2B);
+            }
+            const unsigned long long fm = __ballot(fin);
+            if (lane == 0 && fm) atomicAdd(&s_nacc, __popcll(fm));
+        }
+        __syncthreads();
+        A = s_nacc;
+        if (A == 0) {
+            // nothing could be decided (the candidate list overflowed above the best candidate): one literal step
+            if (tid == 0) {
+                const int w = start_n + rel_of(gtop, Bref, log2B);
+                ax[0] = xyz[(size_t)w * 3 + 0]; ay[0] = xyz[(size_t)w * 3 + 1]; az[0] = xyz[(size_t)w * 3 + 2];
+                idx[start_m + done] = w;
+            }
+            A = 1;
+            __syncthreads();
+        }
+        done += A;
+        stamp(8);  // 8: bounds, ranks, output
+    }
+    if (STAMP && dbg && tid == 0)
+        for (int i = 0; i < 12; i++) dbg[blockIdx.x * 12 + i] = c_ph[i];
+}
+
+void fps_lazy_launch(int b, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset, float4 *pts, const unsigned *rank,
+                     const int *prev_idx, const int *prev_offset, const int *verified, int *idx, hipStream_t st) {
+    if (getenv("P2_FPS_STAMPS")) {  // diagnostic only: synchronous, prints the phase cycles of wave 0 to stderr
+        unsigned long long *dbg = nullptr, host[12];
+        (void)hipMalloc(&dbg, sizeof(host) * b);
+        (void)hipMemset(dbg, 0, sizeof(host) * b);
+        hipLaunchKernelGGL(fps_lazy_kernel<true>, dim3(b), dim3(LZ_NT), 0, st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
+                           verified, idx, dbg);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+        (void)hipFree(dbg);
+        fprintf(stderr, "[fps lazy] rounds %llu samples %llu | cycles: setup %llu sbtests %llu owntests %llu updates %llu maxima+wait %llu gather %llu pairwise %llu "
+                        "fixedpoint %llu output %llu\n", host[10], host[11], host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], host[8]);
+        return;
+    }
+    hipLaunchKernelGGL(fps_lazy_kernel<false>, dim3(b), dim3(LZ_NT), 0, st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
+                       verified, idx, (unsigned long long *)nullptr);
+}
+
+}  // namespace p2

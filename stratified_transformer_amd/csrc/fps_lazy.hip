@@ -36,6 +36,8 @@ constexpr int LZ_CAP = 512;              // candidates / accepted samples per ro
 constexpr int LZ_WORDS = LZ_CAP / 32;
 constexpr int LZ_TARGET = 352;           // candidates the threshold controller aims at
 constexpr int LZ_MAXSB = LZ_NBL * 64;    // super-buckets: the 16 buckets (one per wave) with the same (slot, lane)
+constexpr int LZ_GRID = 1024;            // hash cells of the candidate grid
+constexpr int LZ_HITS = 8;               // listed hitters per candidate
 
 __device__ __forceinline__ unsigned ord_bits(float v) {  // order-preserving float -> unsigned
     const unsigned b = __float_as_uint(v);
@@ -71,9 +73,14 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     constexpr int NW = LZ_NW, NT = LZ_NT, NBL = LZ_NBL, CAP = LZ_CAP, WORDS = LZ_WORDS;
     __shared__ float cx[CAP], cy[CAP], cz[CAP], cd[CAP];  // candidates
     __shared__ unsigned clo[CAP];
-    __shared__ unsigned hit[CAP][WORDS];
-    __shared__ int gtc[CAP];                                // candidates with a larger key
-    __shared__ unsigned short dlist[CAP];                   // dropped candidates
+    __shared__ unsigned long long skey[CAP];                // candidate keys, sorted descending (the reference's selection order)
+    __shared__ unsigned short sidx[CAP];                    // sorted position -> candidate slot
+    __shared__ unsigned ccell[CAP];                         // candidate's grid cell (10 bits per axis), by sorted position
+    __shared__ float4 sp4[CAP];                             // candidate (x, y, z, min-dist), by sorted position
+    __shared__ int ghead[LZ_GRID];                          // hash grid over the candidates: chains of sorted positions
+    __shared__ short gnext[CAP];
+    __shared__ unsigned short hl[CAP][LZ_HITS];             // hitters of a candidate (sorted positions, all with larger keys)
+    __shared__ unsigned char hcnt[CAP];                     // their number; > LZ_HITS: too many to list
     __shared__ float ax[CAP], ay[CAP], az[CAP];            // accepted samples, in selection order
     __shared__ unsigned sbhit[LZ_MAXSB][WORDS];            // accepted samples that may reach a super-bucket
     __shared__ unsigned sbmax[2][LZ_MAXSB];                // largest min-dist (bits) inside a super-bucket, double-buffered
@@ -81,7 +88,8 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     __shared__ unsigned accw[2][WORDS];
     __shared__ unsigned long long wkey[NW];
     __shared__ unsigned long long s_tover, s_tdrop;
-    __shared__ int s_cnt, s_nd, s_nacc, s_changed[2];
+    __shared__ int s_cnt, s_nacc, s_changed[2];
+    __shared__ unsigned s_org[3];                           // cloud origin (ord_bits of the bounding box minimum)
 
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
@@ -152,8 +160,10 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             atomicMax(&sbbox[sb][3], ord_bits(mxx[s])); atomicMax(&sbbox[sb][4], ord_bits(mxy[s])); atomicMax(&sbbox[sb][5], ord_bits(mxz[s]));
             atomicMax(&sbmax[0][sb], (unsigned)(key[s] >> 32));
         }
+    if (tid < 3) s_org[tid] = 0xffffffffu;
     if (tid == 0 && done == 0) idx[start_m] = start_n;
     __syncthreads();  // boxes complete; the idx[] copies above are ordered before the read below
+    if (tid < 3 * LZ_MAXSB) atomicMin(&s_org[tid % 3], sbbox[tid / 3][tid % 3]);
     // the last selected sample has not been applied to the min-dist field yet (fps_bucket.hip's convention; applying a
     // sample twice is harmless): it is the first round's accepted set
     {
@@ -166,7 +176,8 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     }
     done = max(done, 1);
     int A = 1;                                   // accepted samples waiting to be applied
-    float frac = fminf(0.5f, 2.0f * LZ_TARGET / (float)n);  // threshold = top min-dist * (1 - frac)
+    int target = 64, lastK = 0;                  // candidates the threshold controller aims at: grows while most candidates are accepted
+    float frac = fminf(0.5f, 2.0f * 64 / (float)n);  // threshold = top min-dist * (1 - frac)
     int buf = 0;                                 // sbmax[buf] = current super-bucket maxima
     __syncthreads();
 
@@ -272,8 +283,8 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
                 if (mnx[s] != INFINITY) atomicMax(&sbmax[buf ^ 1][s * 64 + lane], (unsigned)(key[s] >> 32));
         }
         buf ^= 1;
-        if (tid == 0) { s_cnt = 0; s_tover = 0ull; s_tdrop = 0ull; s_nd = 0; s_nacc = 0; s_changed[0] = 0; s_changed[1] = 0; }
-        for (int t = tid; t < CAP; t += NT) gtc[t] = 0;
+        if (tid == 0) { s_cnt = 0; s_tover = 0ull; s_tdrop = 0ull; s_nacc = 0; s_changed[0] = 0; s_changed[1] = 0; }
+        for (int t = tid; t < LZ_GRID; t += NT) ghead[t] = -1;
         __syncthreads();
         stamp(4);  // 4: maxima + barrier (waiting for the slowest wave's updates)
         if (done >= m) break;  // (uniform) everything selected, and applied
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             const int found = s_cnt;
             K = min(found, CAP);
             // threshold controller (every thread computes the same): aim at LZ_TARGET candidates
-            const float ratio = fminf(fmaxf((float)LZ_TARGET / (float)max(found, 1), 0.5f), 2.0f);
+            const float ratio = fminf(fmaxf((float)target / (float)max(found, 1), 0.5f), 2.0f);
             if (found > CAP && attempt < 2 && frac > 1e-7f) {
                 frac *= 0.25f * (float)CAP / (float)found;
                 __syncthreads();  // everybody has read s_cnt
@@ -338,39 +349,87 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             break;
         }
         stamp(5);  // 5: gather
-        const int nwK = (K + 31) >> 5;
         const unsigned long long tover = s_tover;
-        // ---- pairwise: hit[j][i] = key_i > key_j && d(i, j) < d_j; gtc[j] = candidates with a larger key ----
-        for (int u = tid; u < K * nwK; u += NT) {
-            const int j = u / nwK, w = u - j * nwK;
-            const float xj = cx[j], yj = cy[j], zj = cz[j], dj = cd[j];
-            const unsigned hj = __float_as_uint(dj), lj = clo[j];
-            unsigned bits = 0u;
-            int gt = 0;
-            const int i0 = w * 32, i1 = min(K, i0 + 32);
-            for (int i = i0; i < i1; i++) {
-                const unsigned hi = __float_as_uint(cd[i]);
-                const bool before = hi > hj || (hi == hj && clo[i] > lj);
-                gt += before ? 1 : 0;
-                if (before && sqd(xj - cx[i], yj - cy[i], zj - cz[i]) < dj) bits |= 1u << (i - i0);
+        lastK = K;
+        // ---- sort the candidates by key, descending: sorted position = the order the reference would select them in ----
+        int P2 = 2;
+        while (P2 < K) P2 <<= 1;
+        if (tid < P2) {
+            skey[tid] = tid < K ? (((unsigned long long)__float_as_uint(cd[tid]) << 32) | clo[tid]) : 0ull;
+            sidx[tid] = (unsigned short)tid;
+        }
+        __syncthreads();
+        for (int kk = 2; kk <= P2; kk <<= 1)
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                const int other = tid ^ jj;
+                if (tid < P2 && other > tid) {
+                    const unsigned long long a = skey[tid], b = skey[other];
+                    if ((a < b) == ((tid & kk) == 0)) {  // descending overall
+                        skey[tid] = b; skey[other] = a;
+                        const unsigned short t0 = sidx[tid];
+                        sidx[tid] = sidx[other]; sidx[other] = t0;
+                    }
+                }
+                __syncthreads();
             }
-            hit[j][w] = bits;
-            if (gt) atomicAdd(&gtc[j], gt);
+        stamp(6);  // 6: sort
+        // ---- hitters through a hash grid.  hit(r, r2) = r2 < r (larger key) && d(r2, r) < d_r needs |p_r - p_r2| < sqrt(d_top) per
+        //      axis: with cells of that edge (plus slack for the rounding of the cell index) only the 27 cells around a
+        //      candidate can hold a hitter ----
+        const float cell = sqrtf(dtop) * 1.002f + 1e-30f, inv_cell = 1.0f / cell;
+        const float ox = ord_float(s_org[0]), oy = ord_float(s_org[1]), oz = ord_float(s_org[2]);
+        float px = 0.f, py = 0.f, pz = 0.f, pd = 0.f;
+        int gx = 0, gy = 0, gz = 0;
+        auto cell_hash = [](int x, int y, int z) -> unsigned {
+            return ((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (LZ_GRID - 1);
+        };
+        if (tid < K) {
+            const int c = sidx[tid];
+            px = cx[c]; py = cy[c]; pz = cz[c]; pd = cd[c];
+            gx = min(max((int)floorf((px - ox) * inv_cell), 0), 1022);  // (clamped cells only merge: still a superset)
+            gy = min(max((int)floorf((py - oy) * inv_cell), 0), 1022);
+            gz = min(max((int)floorf((pz - oz) * inv_cell), 0), 1022);
+            ccell[tid] = (unsigned)gx | ((unsigned)gy << 10) | ((unsigned)gz << 20);
+            sp4[tid] = make_float4(px, py, pz, pd);
+            gnext[tid] = (short)atomicExch(&ghead[cell_hash(gx, gy, gz)], tid);
+        }
+        __syncthreads();
+        int nh = 0;
+        if (tid < K) {
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int qx = gx + dx, qy = gy + dy, qz = gz + dz;
+                        if (qx < 0 || qy < 0 || qz < 0) continue;
+                        const unsigned want = (unsigned)qx | ((unsigned)qy << 10) | ((unsigned)qz << 20);
+                        for (int r2 = ghead[cell_hash(qx, qy, qz)]; r2 >= 0; r2 = gnext[r2]) {
+                            if (r2 >= tid || ccell[r2] != want) continue;  // smaller key, or another cell of the same hash chain
+                            const float4 q = sp4[r2];
+                            if (sqd(px - q.x, py - q.y, pz - q.z) < pd) {
+                                if (nh < LZ_HITS) hl[tid][nh] = (unsigned short)r2;
+                                nh++;
+                            }
+                        }
+                    }
+            hcnt[tid] = (unsigned char)min(nh, 255);
         }
         if (tid < WORDS) {
             const int lo = tid * 32;
             accw[0][tid] = K >= lo + 32 ? 0xffffffffu : (K > lo ? ((1u << (K - lo)) - 1u) : 0u);
         }
         __syncthreads();
-        stamp(6);  // 6: pairwise
-        // ---- resolve: fixed point of acc_j = !exists i: hit[j][i] && acc_i ----
+        stamp(7);  // 7: hitters
+        // ---- resolve: fixed point of acc_r = !exists r2 in hitters(r): acc_r2  (a candidate with more hitters than the list holds
+        //      is simply not decided in this round) ----
         int cur = 0;
         for (int it = 0; it < CAP; it++) {
             bool mine = false, old = false;
             if (tid < K) {
-                unsigned h = 0u;
-                for (int w = 0; w < nwK; w++) h |= hit[tid][w] & accw[cur][w];
-                mine = h == 0u;
+                mine = nh <= LZ_HITS;
+                for (int t = 0; t < min(nh, LZ_HITS); t++) {
+                    const int r2 = hl[tid][t];
+                    mine = mine && !((accw[cur][r2 >> 5] >> (r2 & 31)) & 1u);
+                }
                 old = (accw[cur][tid >> 5] >> (tid & 31)) & 1u;
             }
             const unsigned long long bm = __ballot(mine);
@@ -384,45 +443,48 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             cur ^= 1;
             if (!s_changed[it & 1]) break;  // uniform: read after the barrier, reset two iterations later
         }
-        stamp(7);  // 7: fixed point
-        // ---- dropped candidates bound what may still be accepted ----
+        stamp(8);  // 8: fixed point
+        // ---- what was not accepted bounds what may be: a dropped candidate's new key is at most its key at the distance to
+        //      the accepted candidates that hit it; an undecided one keeps its key ----
         bool acc = false;
         unsigned long long kj = 0ull;
         if (tid < K) {
             acc = (accw[cur][tid >> 5] >> (tid & 31)) & 1u;
-            kj = ((unsigned long long)__float_as_uint(cd[tid]) << 32) | clo[tid];
+            kj = skey[tid];
             if (!acc) {
-                float nd = cd[tid];
-                for (int w = 0; w < nwK; w++) {
-                    unsigned bits = hit[tid][w] & accw[cur][w];
-                    while (bits) {
-                        const int i = w * 32 + __ffs(bits) - 1;
-                        bits &= bits - 1;
-                        nd = fminf(nd, sqd(cx[tid] - cx[i], cy[tid] - cy[i], cz[tid] - cz[i]));
+                float nd = pd;
+                bool any = false;
+                for (int t = 0; t < min(nh, LZ_HITS); t++) {
+                    const int r2 = hl[tid][t];
+                    if ((accw[cur][r2 >> 5] >> (r2 & 31)) & 1u) {
+                        const float4 q = sp4[r2];
+                        nd = fminf(nd, sqd(px - q.x, py - q.y, pz - q.z));
+                        any = true;
                     }
                 }
-                atomicMax(&s_tdrop, ((unsigned long long)__float_as_uint(nd) << 32) | clo[tid]);
-                dlist[atomicAdd(&s_nd, 1)] = (unsigned short)tid;
+                if (nh > LZ_HITS || !any) nd = pd;
+                atomicMax(&s_tdrop, ((unsigned long long)__float_as_uint(nd) << 32) | (unsigned)kj);
             }
         }
         __syncthreads();
         {
             const unsigned long long tcut = tover > s_tdrop ? tover : s_tdrop;
             const int remaining = m - done;
-            bool fin = acc && kj > tcut;
-            int r = 0;
-            if (fin) {
-                r = gtc[tid];
-                const int nd_ = s_nd;
-                for (int t = 0; t < nd_; t++) {
-                    const int i = dlist[t];
-                    const unsigned long long ki = ((unsigned long long)__float_as_uint(cd[i]) << 32) | clo[i];
-                    r -= ki > kj ? 1 : 0;
-                }
-                fin = r < remaining;
+            const bool fin0 = acc && kj > tcut;  // keys descend with the position: the accepted set is a prefix of the acc set
+            const unsigned long long fm0 = __ballot(fin0);
+            if (lane == 0 && wave * 2 < WORDS) {
+                accw[cur ^ 1][wave * 2] = (unsigned)fm0;
+                accw[cur ^ 1][wave * 2 + 1] = (unsigned)(fm0 >> 32);
             }
+            __syncthreads();
+            int r = 0;  // accepted candidates in front of this one = its place in the selection order
+            if (fin0) {
+                for (int w = 0; w < (tid >> 5); w++) r += __popc(accw[cur ^ 1][w]);
+                r += __popc(accw[cur ^ 1][tid >> 5] & ((1u << (tid & 31)) - 1u));
+            }
+            const bool fin = fin0 && r < remaining;
             if (fin) {
-                ax[r] = cx[tid]; ay[r] = cy[tid]; az[r] = cz[tid];
+                ax[r] = px; ay[r] = py; az[r] = pz;
                 idx[start_m + done + r] = start_n + rel_of(kj, Bref, log2B);
             }
             const unsigned long long fm = __ballot(fin);
@@ -430,6 +492,9 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
         }
         __syncthreads();
         A = s_nacc;
+        // few candidates while they get in each other's way (the early rounds), many once most of them are accepted
+        if (A * 2 > lastK) target = min(target + target / 2, LZ_TARGET);
+        else if (A * 4 < lastK) target = max(target / 2, 32);
         if (A == 0) {
             // nothing could be decided (the candidate list overflowed above the best candidate): one literal step
             if (tid == 0) {
@@ -441,7 +506,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             __syncthreads();
         }
         done += A;
-        stamp(8);  // 8: bounds, ranks, output
+        stamp(9);  // 9: bounds, ranks, output
     }
     if (STAMP && dbg && tid == 0)
         for (int i = 0; i < 12; i++) dbg[blockIdx.x * 12 + i] = c_ph[i];
@@ -458,8 +523,9 @@ void fps_lazy_launch(int b, int Bref, int log2B, const float *xyz, const int *of
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
         (void)hipFree(dbg);
-        fprintf(stderr, "[fps lazy] rounds %llu samples %llu | cycles: setup %llu sbtests %llu owntests %llu updates %llu maxima+wait %llu gather %llu pairwise %llu "
-                        "fixedpoint %llu output %llu\n", host[10], host[11], host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], host[8]);
+        fprintf(stderr, "[fps lazy] rounds %llu samples %llu | cycles: setup %llu sbtests %llu owntests %llu updates %llu maxima+wait %llu gather %llu sort %llu "
+                        "hitters %llu fixedpoint %llu output %llu\n", host[10], host[11], host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], host[8],
+                host[9]);
         return;
     }
     hipLaunchKernelGGL(fps_lazy_kernel<false>, dim3(b), dim3(LZ_NT), 0, st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,

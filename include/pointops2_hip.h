@@ -110,8 +110,10 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher(int N, int M, int
 /* rpe_v2/relative_pos_encoding_cuda_kernel_v2.h:22-29 — CSR forms.  table [L,h,hdim,3]; rel_idx [M,3].
  * hdim must be 16 or 32.  backward: grad_q / grad_attn fully written; grad_k / grad_v / table grads
  * ACCUMULATE (pre-zeroed by the caller).  The table length L is not part of the reference signature
- * but the kernels stage the tables in LDS: call pointops2_set_table_rows(L) before any *_v3 bias or
- * *_v2 rel-pos-value launcher (forward and backward); without it the call records an error. */
+ * but the fast kernels stage the tables in LDS: announce it with pointops2_set_table_rows(L) before any
+ * *_v3 bias or *_v2 rel-pos-value launcher (forward and backward).  Without it the launchers are still
+ * callable with the reference's arguments alone: generic kernels then read the tables from global
+ * memory and accumulate with atomics as the reference does (same results, several times slower). */
 void dot_prod_with_idx_forward_cuda_launcher_v2(int N, int M, int h, int hdim, int n_max, int T, const float *q,
                                                 const int *index_q, const float *k, const int *index_k,
                                                 const float *table_q, const float *table_k, const int *rel_idx,
@@ -139,6 +141,18 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
                                                                   const int *index1, const float *attn, const float *v,
                                                                   const float *table, const int *rel_idx,
                                                                   float *grad_attn, float *grad_v, float *grad_table);
+
+/* subtraction/subtraction_cuda_kernel.h:14-15, aggregation/aggregation_cuda_kernel.h:14-15 — Point-Transformer
+ * vector-attention ops bound by pointops_api.cpp:23-26 and called by no model of the reference (out of scope):
+ * exported so that the reference's shim sources link; a call records an error and does nothing. */
+void subtraction_forward_cuda_launcher(int n, int nsample, int c, const float *input1, const float *input2, const int *idx, float *output);
+void subtraction_backward_cuda_launcher(int n, int nsample, int c, const int *idx, const float *grad_output, float *grad_input1,
+                                        float *grad_input2);
+void aggregation_forward_cuda_launcher(int n, int nsample, int c, int w_c, const float *input, const float *position, const float *weight,
+                                       const int *idx, float *output);
+void aggregation_backward_cuda_launcher(int n, int nsample, int c, int w_c, const float *input, const float *position, const float *weight,
+                                        const int *idx, const float *grad_output, float *grad_input, float *grad_position,
+                                        float *grad_weight);
 
 /* ------------------------------------------------------------------------------------------ */
 /* PART 2 — additional entry points of this build                                             */
@@ -286,6 +300,25 @@ void cell_attention_backward_launcher(const pointops2_cell_plan *plan, int h, in
                                       const float *k, const float *v, const float *out, const float *table_q, const float *table_k,
                                       const float *table_v, const float *pbuf, float *gsbuf, float *grad_q, float *grad_k,
                                       float *grad_v, float *grad_table_q, float *grad_table_k, float *grad_table_v);
+
+/* ---- the data-side step in front of the path ----
+ * voxel keys of util/voxelize.py:46-59,79-84 (floor(coord / voxel), the FNV-style 64-bit hash of the three cells) and the
+ * crop distances of util/data_util.py:188-191 (squared distance to the seed point), in the coordinates' own precision
+ * (is_f64: coord / dist are double arrays, else float). */
+void pointops2_voxel_keys_launcher(int N, int is_f64, const void *coord, double voxel, unsigned long long *keys);
+void pointops2_crop_dist_launcher(int N, int is_f64, const void *coord, int seed, void *dist);
+
+/* The same two entry points with q / k / v / tables STORED as bf16 (raw 16-bit patterns; BASELINE config 3's second leg).
+ * Arithmetic, outputs (out, pbuf) and all gradients stay fp32: the reference's operators are fp32-only
+ * (model/stratified_transformer.py:183,194,208 cast every operand with .float()), so this is an extension whose parity
+ * target is "the fp32 path on the bf16-rounded operands" (identical up to summation order). */
+void cell_attention_forward_bf16_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const uint16_t *q, const uint16_t *k,
+                                          const uint16_t *v, const uint16_t *table_q, const uint16_t *table_k, const uint16_t *table_v,
+                                          float *out, float *ml, float *pbuf);
+void cell_attention_backward_bf16_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const float *grad_out, const uint16_t *q,
+                                           const uint16_t *k, const uint16_t *v, const float *out, const uint16_t *table_q,
+                                           const uint16_t *table_k, const uint16_t *table_v, const float *pbuf, float *gsbuf, float *grad_q,
+                                           float *grad_k, float *grad_v, float *grad_table_q, float *grad_table_k, float *grad_table_v);
 
 #ifdef __cplusplus
 }

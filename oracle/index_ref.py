@@ -185,3 +185,68 @@ def build_stage_indices(xyz, offset, window_size, quant_size, downsample_idx, bl
     rel = rel_pos_index(xyz, i0, i1, window_size, quant_size, div_mode)
     return dict(index_0=i0, index_1=i1, offsets=offsets, n_max=n_max, rel_idx=rel,
                 p2v_map=p2v, counts=cnt, new_p2v_map=np2v, new_counts=ncnt)
+
+
+# ---------------------------------------------------------------------------------------------
+# Swin3D variant (model/swin3d_transformer.py): dense window pairs only, in-window quantised coordinates
+# ---------------------------------------------------------------------------------------------
+def swin_rel_pos_index(xyz, index_0, index_1, window_size, quant_size, shift):
+    """swin3d_transformer.py:151-154 + map_func :129-130 -> [M,3] in [0, 2*int(window/quant) - 2]"""
+    qgl = int(window_size / quant_size)  # :109
+    xyz_quant = (xyz - xyz.min(0)[0] + shift) % window_size
+    xyz_quant = xyz_quant // quant_size
+    return (xyz_quant[index_0.long()] - xyz_quant[index_1.long()] + qgl - 1).int()
+
+
+def swin_stage_indices(xyz, offset, window_size, quant_size, block_parity):
+    """BasicLayer.forward of the Swin3D variant for one block (:239-278: every pair of points of one window; the odd
+    blocks on the partition shifted by half a window), CSR with a stable sort, and the block's rel-pos index."""
+    batch = batch_from_offset(offset)
+    ws = torch.tensor([window_size] * 3).type_as(xyz)
+    if block_parity % 2 == 0:
+        _, p2v, cnt = grid_sample(xyz, batch, ws, None)
+        shift = 0.0
+    else:
+        _, p2v, cnt = grid_sample(xyz + 1 / 2 * ws, batch, ws, xyz.min(0)[0])
+        shift = 1 / 2 * ws
+    n, k = p2v.shape
+    mask = torch.arange(k).unsqueeze(0) < cnt.unsqueeze(-1)
+    mask_mat = mask.unsqueeze(-1) & mask.unsqueeze(-2)
+    i0 = p2v.unsqueeze(-1).expand(-1, -1, k)[mask_mat]
+    i1 = p2v.unsqueeze(1).expand(-1, k, -1)[mask_mat]
+    i0, i1, offsets, n_max = csr_from_pairs(i0, i1, xyz.shape[0])
+    return dict(index_0=i0, index_1=i1, offsets=offsets, n_max=n_max, rel_idx=swin_rel_pos_index(xyz, i0, i1, window_size, quant_size, shift))
+
+
+# ---------------------------------------------------------------------------------------------
+# data-side step (util/voxelize.py, util/data_util.py) - numpy, stable sorts (the reference's argsort is unstable: the
+# order inside a voxel / among equal distances is unspecified there; ascending index is one of its valid outputs)
+# ---------------------------------------------------------------------------------------------
+def fnv_hash_vec(arr):
+    """util/voxelize.py:46-59"""
+    import numpy as np
+    arr = arr.copy().astype(np.uint64, copy=False)
+    hashed = np.uint64(14695981039346656037) * np.ones(arr.shape[0], dtype=np.uint64)
+    for j in range(arr.shape[1]):
+        hashed *= np.uint64(1099511628211)
+        hashed = np.bitwise_xor(hashed, arr[:, j])
+    return hashed
+
+
+def voxelize(coord, voxel_size, mode=0, rand=None):
+    """util/voxelize.py:79-95 with a stable argsort and the random draw passed in"""
+    import numpy as np
+    discrete = np.floor(coord / np.asarray(voxel_size, dtype=coord.dtype))
+    key = fnv_hash_vec(discrete)
+    idx_sort = np.argsort(key, kind="stable")
+    _, count = np.unique(key[idx_sort], return_counts=True)
+    if mode == 0:
+        sel = np.cumsum(np.insert(count, 0, 0)[0:-1]) + rand % count
+        return idx_sort[sel]
+    return idx_sort, count
+
+
+def crop_nearest(coord, voxel_max, seed_index):
+    """util/data_util.py:188-191"""
+    import numpy as np
+    return np.argsort(np.sum(np.square(coord - coord[seed_index]), 1), kind="stable")[:voxel_max]

@@ -91,6 +91,35 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset):
     return idx, np.sqrt(dist2)
 
 
+def ball_query(radius, max_num, x, y, offset_x, offset_y):
+    """train_backup.py:362-364 `tp.ball_query(radius, max_num, x, y, mode="partial_dense", ...)[0]` (torch_points_kernels 0.6.10:
+    third-party, absent from the reference tree - PARITY UNPINNED; restated from its published behaviour): per point of y up
+    to max_num points of x of the same batch element with squared distance < radius^2, nearest first, padded with -1.
+    Brute force: every candidate's squared distance with the kNN kernel's fma chain, a stable sort by (distance, index)."""
+    x, y = _f(x), _f(y)
+    offset_x, offset_y = _i(offset_x), _i(offset_y)
+    r2 = np.float32(radius) * np.float32(radius)
+    m = y.shape[0]
+    idx = np.full((m, max_num), -1, np.int32)
+    d2o = np.full((m, max_num), -1.0, np.float32)
+    xs, ys = 0, 0
+    for b in range(len(offset_x)):
+        xe, ye = int(offset_x[b]), int(offset_y[b])
+        xb = x[xs:xe].astype(np.float64)
+        for i in range(ys, ye):
+            d = (y[i].astype(np.float64) - xb)  # exact differences in f64, then the f32 fma chain: fma(dz,dz, fma(dx,dx, dy*dy))
+            dx, dy, dz = (d[:, a].astype(np.float32) for a in range(3))
+            t = (dy * dy).astype(np.float32)
+            t = (dx.astype(np.float64) * dx.astype(np.float64) + t.astype(np.float64)).astype(np.float32)
+            dd = (dz.astype(np.float64) * dz.astype(np.float64) + t.astype(np.float64)).astype(np.float32)
+            order = np.lexsort((np.arange(xe - xs), dd))[:max_num]
+            keep = order[dd[order] < r2]
+            idx[i, : len(keep)] = keep + xs
+            d2o[i, : len(keep)] = dd[keep]
+        xs, ys = xe, ye
+    return idx, d2o
+
+
 def attention_step1_v2(q, k, index1, index0_offsets):
     q, k, index1, index0_offsets = _f(q), _f(k), _i(index1), _i(index0_offsets)
     N, h, d = q.shape

@@ -51,6 +51,10 @@ SIGNATURES = {
     "dot_prod_with_idx_backward_cuda_launcher_v3": [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "attention_step2_with_rel_pos_value_forward_cuda_launcher_v2": [I, I, I, I, I, P, P, P, P, P, P, P],
     "attention_step2_with_rel_pos_value_backward_cuda_launcher_v2": [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P],
+    "subtraction_forward_cuda_launcher": [I, I, I, P, P, P, P],
+    "subtraction_backward_cuda_launcher": [I, I, I, P, P, P, P],
+    "aggregation_forward_cuda_launcher": [I, I, I, I, P, P, P, P, P],
+    "aggregation_backward_cuda_launcher": [I, I, I, I, P, P, P, P, P, P, P, P],
     "segment_softmax_forward_launcher": [I, I, I, P, P, P],
     "window_logits_softmax_forward_launcher": [I, I, I, I, P, P, P, P, P, P, P, P],
     "window_attention_backward_launcher": [I, I, I, I] + [P] * 18,
@@ -62,10 +66,14 @@ SIGNATURES = {
     "pointops2_sampled_buckets_launcher": [I, I, P, P, P, P, P, P, P, P, Z],
     "pointops2_pairs_count_launcher": [I, P, P, P, P, P, P, P, P, Z],
     "pointops2_pairs_fill_launcher": [I, P, F, F, P, P, P, P, P, P, P, P, P, P, P],
+    "pointops2_voxel_keys_launcher": [I, I, P, ctypes.c_double, P],
+    "pointops2_crop_dist_launcher": [I, I, P, I, P],
     "pointops2_cell_plan_count_launcher": [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z],
     "pointops2_cell_plan_fill_launcher": [I, P, F, F, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "cell_attention_forward_launcher": [P, I, I, I] + [P] * 9,
     "cell_attention_backward_launcher": [P, I, I, I] + [P] * 16,
+    "cell_attention_forward_bf16_launcher": [P, I, I, I] + [P] * 9,
+    "cell_attention_backward_bf16_launcher": [P, I, I, I] + [P] * 16,
 }
 # entry points with a non-void result
 RESULTS = {

@@ -39,6 +39,17 @@ def _scatter_softmax_generic(src, index, dim, eps):
     return ex / (sm + eps).gather(dim, index)
 
 
+_ASSUME_MODEL_ORDER = False
+
+
+def assume_model_call_order(flag=True):
+    """Declare that scatter_softmax is only called the way model/stratified_transformer.py:183-205 calls it (right after
+    attention_step1_v2 / dot_prod_with_idx_v3 on the same pair list, `index` = the sorted per-pair query ids): the shim then
+    never synchronises the host.  Off by default: the shim then keeps torch_scatter's full semantics for any index."""
+    global _ASSUME_MODEL_ORDER
+    _ASSUME_MODEL_ORDER = bool(flag)
+
+
 def scatter_softmax(src, index, dim=-1, eps=1e-12):
     """Same signature as torch_scatter.scatter_softmax.  The model's call site
     (model/stratified_transformer.py:205: src [M,h] fp32 on the GPU, index = ascending index_0,
@@ -47,6 +58,21 @@ def scatter_softmax(src, index, dim=-1, eps=1e-12):
         raise ValueError("`scatter_softmax` can only be computed over tensors with floating point data types.")
     d = dim if dim >= 0 else src.dim() + dim
     if src.is_cuda and src.dim() == 2 and index.dim() == 1 and d == 0 and src.dtype == torch.float32 and index.numel() > 0:
+        from .. import _lib, pointops as P
+        # The model calls this right after A1 / A2 on the same pair list (:183-205): the CSR offsets those operators just
+        # used describe `index`.  That is CHECKED on the device (expand the offsets, compare); the verdict is read back -
+        # one host sync, which torch_scatter itself pays for `index.max()` - unless the caller has declared the model's
+        # call order with assume_model_call_order(True): then nothing is read back and a mismatch poisons the result's
+        # first row with NaN instead of taking the generic path.  Either way the offsets are not rebuilt.
+        offsets = P.last_csr(src.device.index, index.numel())
+        if offsets is not None:
+            expect = torch.empty(index.numel(), dtype=torch.int32, device=src.device)
+            _lib.call("csr_expand_launcher", int(offsets.shape[0]) - 1, int(index.numel()), _lib.ptr(offsets), _lib.ptr(expect), device=src.device)
+            same = (expect == index).all()
+            if _ASSUME_MODEL_ORDER:
+                return P.segment_softmax(src, offsets, same)
+            if bool(same):
+                return P.segment_softmax(src, offsets)
         # ascending index <=> segments are contiguous runs; one host sync, like the model's own asserts (:189-190)
         if bool((index[1:] >= index[:-1]).all()):
             from ..pointops import segment_softmax

@@ -135,12 +135,32 @@ __device__ __forceinline__ void bstore_floats(rsrc_t r, int off, const float (&f
     }
 }
 
+// ---- storage type of q / k / v / tables: fp32, or bf16 (BASELINE config 3's second leg: bf16 storage, fp32 arithmetic;
+// the reference's operators are fp32-only, stratified_transformer.py:183,194,208 `.float()`) ----
+typedef unsigned short bf16_t;  // raw bits
+__device__ __forceinline__ float4 ld_row4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld_row4(const bf16_t *p) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);  // four bf16: widening to fp32 is a shift
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float ld_elem(const float *p) { return *p; }
+__device__ __forceinline__ float ld_elem(const bf16_t *p) { return __uint_as_float((unsigned)*p << 16); }
+// image of one head's table: [axis][row][16] elements of T (global layout [L, h, 16, 3])
+template <typename T>
+__device__ __forceinline__ void stage_table_t(T *lds, const T *__restrict__ tab, int L, int h, int head) {
+    const int total = 3 * L * 16;
+    for (int x = threadIdx.x; x < total; x += blockDim.x) {
+        const int i = x % 16, r = (x / 16) % L, ax = x / (16 * L);
+        lds[x] = tab[(((size_t)r * h + head) * 16 + i) * 3 + ax];
+    }
+}
+
 // ---- LDS image of a head's three tables: table TB at float offset TB * TS (TS a compile-time constant, so that the
 // three tables of one (axis, row) differ by an immediate offset), inside a table [axis][row][16] ----
 template <int LCAP>
 struct TabGeo {
-    static constexpr int TS = 3 * LCAP * 16;  // floats per table image
-    static constexpr size_t bytes() { return (size_t)3 * TS * sizeof(float); }
+    static constexpr int TS = 3 * LCAP * 16;  // elements per table image
+    static constexpr size_t bytes(size_t elem) { return (size_t)3 * TS * elem; }
 };
 struct RowOff {
     int o0, o1, o2;
@@ -163,12 +183,12 @@ __device__ __forceinline__ float4 tsum_at(const float *lds, RowOff r) {
 struct Rows3 {
     float4 a, b, c;
 };
-template <int OFF>
-__device__ __forceinline__ Rows3 rows_at(const float *lds, RowOff r) {
+template <int OFF, typename T>
+__device__ __forceinline__ Rows3 rows_at(const T *lds, RowOff r) {
     Rows3 x;
-    x.a = *reinterpret_cast<const float4 *>(lds + OFF + r.o0);
-    x.b = *reinterpret_cast<const float4 *>(lds + OFF + r.o1);
-    x.c = *reinterpret_cast<const float4 *>(lds + OFF + r.o2);
+    x.a = ld_row4(lds + OFF + r.o0);
+    x.b = ld_row4(lds + OFF + r.o1);
+    x.c = ld_row4(lds + OFF + r.o2);
     return x;
 }
 // T(m)[4c..4c+3] = tab[r0,.,.,0] + tab[r1,.,.,1] + tab[r2,.,.,2]   (left to right, as the reference), as packed
@@ -228,8 +248,9 @@ __device__ __forceinline__ void dispatch_passes(int np, F f) {
     }
 }
 
+template <typename T>
 struct LaneCtx {
-    const float *lds;
+    const T *lds;
     int L, lane, p, c, head, h, C, hoff;
 };
 struct CellBufs {
@@ -242,26 +263,26 @@ struct CellBufs {
 // Key slots: lane (p, c) of an NPA-pass instance owns the NPA CONSECUTIVE keys j0 + p * NPA + t, t < NPA, of the chunk, so
 // that its rel-pos words, softmax weights and logit gradients of one query are NPA consecutive dwords = one wide load.
 // Query ids: 64 at a time, one per lane; a query's id is then a v_readlane away (a scalar: the q row address is uniform).
-template <int NPA>
-__device__ __forceinline__ void load_key_rows(const LaneCtx &x, const CellBufs &cb, const float *__restrict__ rows, int j0, float4 (&r4)[NPA]) {
+template <int NPA, typename T>
+__device__ __forceinline__ void load_key_rows(const LaneCtx<T> &x, const CellBufs &cb, const T *__restrict__ rows, int j0, float4 (&r4)[NPA]) {
     unsigned keys[NPA];
     bload_words<NPA>(cb.key, (j0 + x.p * NPA) * 4, keys);  // (past the end: key 0, never used)
 #pragma unroll
-    for (int t = 0; t < NPA; t++) r4[t] = ldg4(rows + (size_t)keys[t] * x.C + x.hoff);
+    for (int t = 0; t < NPA; t++) r4[t] = ld_row4(rows + (size_t)keys[t] * x.C + x.hoff);
 }
 
-template <int NPA, int TS>
-__device__ __forceinline__ void fwd_sweep_logits(const LaneCtx &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p,
-                                                 const float *__restrict__ q, const float *__restrict__ k, float *__restrict__ ml,
+template <int NPA, int TS, typename T>
+__device__ __forceinline__ void fwd_sweep_logits(const LaneCtx<T> &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p,
+                                                 const T *__restrict__ q, const T *__restrict__ k, float *__restrict__ ml,
                                                  int ch, bool single, int j0, int nkc) {
     const int p = x.p, c = x.c;
     const int nvalid = min(max(nkc - p * NPA, 0), NPA);  // this lane's slots inside the chunk
     float4 k4[NPA];
-    load_key_rows<NPA>(x, cb, k, j0, k4);
+    load_key_rows<NPA, T>(x, cb, k, j0, k4);
     // the inputs of query il+1 are requested while query il is worked on
     int ids = (int)bload_u32(cb.qid, x.lane * 4);
     int i_nx = __builtin_amdgcn_readlane(ids, 0);
-    float4 q4_nx = ldg4(q + (size_t)i_nx * x.C + x.hoff);
+    float4 q4_nx = ld_row4(q + (size_t)i_nx * x.C + x.hoff);
     unsigned w_nx[NPA];
     bload_words<NPA>(cb.rel, (j0 + p * NPA) * 4, w_nx);
     for (int il = 0; il < ct.nq; il++) {
@@ -273,19 +294,19 @@ __device__ __forceinline__ void fwd_sweep_logits(const LaneCtx &x, const CellTas
         const int roff = (il * ct.nk + j0 + p * NPA) * 4;
         if (((il + 1) & 63) == 0) ids = (int)bload_u32(cb.qid, (il + 1 + x.lane) * 4);
         i_nx = __builtin_amdgcn_readlane(ids, (il + 1) & 63);  // (past the end: query 0, never used)
-        q4_nx = ldg4(q + (size_t)i_nx * x.C + x.hoff);
+        q4_nx = ld_row4(q + (size_t)i_nx * x.C + x.hoff);
         bload_words<NPA>(cb.rel, roff + ct.nk * 4, w_nx);
         float lg[NPA];
         float mx = -INFINITY;
         RowOff ro = row_off(w[0], x.L, c);
-        Rows3 rq = rows_at<0>(x.lds, ro), rk = rows_at<TS>(x.lds, ro);
+        Rows3 rq = rows_at<0, T>(x.lds, ro), rk = rows_at<TS, T>(x.lds, ro);
 #pragma unroll
         for (int t = 0; t < NPA; t++) {
             Rows3 rq1 = rq, rk1 = rk;
             if (t + 1 < NPA) {
                 ro = row_off(w[t + 1], x.L, c);
-                rq1 = rows_at<0>(x.lds, ro);
-                rk1 = rows_at<TS>(x.lds, ro);
+                rq1 = rows_at<0, T>(x.lds, ro);
+                rk1 = rows_at<TS, T>(x.lds, ro);
             }
             const f32x2c d2 = pdot_acc(k4[t], rsum(rk), pdot_acc(q4, rsum(rq), pdot_acc(q4, k4[t], f32x2c{0.f, 0.f})));
             const float s = quad_sum(d2.x + d2.y);
@@ -324,14 +345,14 @@ __device__ __forceinline__ void fwd_sweep_logits(const LaneCtx &x, const CellTas
     }
 }
 
-template <int NPA, int TS>
-__device__ __forceinline__ void fwd_sweep_values(const LaneCtx &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p,
-                                                 const float *__restrict__ v, const float *__restrict__ ml, float *__restrict__ out,
+template <int NPA, int TS, typename T>
+__device__ __forceinline__ void fwd_sweep_values(const LaneCtx<T> &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p,
+                                                 const T *__restrict__ v, const float *__restrict__ ml, float *__restrict__ out,
                                                  int ch, bool single, int j0, int nkc) {
     const int p = x.p, c = x.c;
     const int nvalid = min(max(nkc - p * NPA, 0), NPA);
     float4 v4[NPA];
-    load_key_rows<NPA>(x, cb, v, j0, v4);
+    load_key_rows<NPA, T>(x, cb, v, j0, v4);
     unsigned w_nx[NPA];
     float a_nx[NPA];
     bload_words<NPA>(cb.rel, (j0 + p * NPA) * 4, w_nx);
@@ -358,11 +379,11 @@ __device__ __forceinline__ void fwd_sweep_values(const LaneCtx &x, const CellTas
             if (c == 0) bstore_floats<NPA>(rs_p, roff, a, nvalid);
         }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        Rows3 rv = rows_at<2 * TS>(x.lds, row_off(w[0], x.L, c));
+        Rows3 rv = rows_at<2 * TS, T>(x.lds, row_off(w[0], x.L, c));
 #pragma unroll
         for (int t = 0; t < NPA; t++) {
             Rows3 rv1 = rv;
-            if (t + 1 < NPA) rv1 = rows_at<2 * TS>(x.lds, row_off(w[t + 1], x.L, c));
+            if (t + 1 < NPA) rv1 = rows_at<2 * TS, T>(x.lds, row_off(w[t + 1], x.L, c));
             const float at = t < nvalid ? a[t] : 0.f;  // (a flagged entry's weight is stored as 0)
             acc = pfma4(at, padd4(rsum(rv), v4[t]), acc);
             rv = rv1;
@@ -376,15 +397,16 @@ __device__ __forceinline__ void fwd_sweep_values(const LaneCtx &x, const CellTas
     }
 }
 
-template <int NP, int LCAP>
-__global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ q,
-                                                                 const float *__restrict__ k, const float *__restrict__ v,
-                                                                 const float *__restrict__ table_q, const float *__restrict__ table_k,
-                                                                 const float *__restrict__ table_v, float *__restrict__ out,
+template <int NP, int LCAP, typename T>
+__global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_plan pl, int h, int L, const T *__restrict__ q,
+                                                                 const T *__restrict__ k, const T *__restrict__ v,
+                                                                 const T *__restrict__ table_q, const T *__restrict__ table_k,
+                                                                 const T *__restrict__ table_v, float *__restrict__ out,
                                                                  float *__restrict__ ml, float *__restrict__ pbuf, size_t plane) {
     constexpr int D = 16, TS = TabGeo<LCAP>::TS;
-    extern __shared__ float lds[];
-    LaneCtx x;
+    extern __shared__ float lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
+    LaneCtx<T> x;
     x.lds = lds;
     x.L = L;
     x.h = h;
@@ -395,9 +417,9 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_
     x.c = x.lane & 3;
     x.hoff = x.head * D + 4 * x.c;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stage_table<D>(lds, table_q, L, h, x.head, 1);
-    stage_table<D>(lds + TS, table_k, L, h, x.head, 1);
-    stage_table<D>(lds + 2 * TS, table_v, L, h, x.head, 1);
+    stage_table_t<T>(lds, table_q, L, h, x.head);
+    stage_table_t<T>(lds + TS, table_k, L, h, x.head);
+    stage_table_t<T>(lds + 2 * TS, table_v, L, h, x.head);
     __syncthreads();
     const int nC = pl.counts[0];
     float *pb = pbuf + (size_t)x.head * plane;
@@ -416,14 +438,14 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_
         for (int ch = 0; ch < nch; ch++) {  // sweep 1: logits and softmax
             const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0);
             dispatch_passes<NP>((nkc + 15) >> 4, [&](auto tag) {
-                fwd_sweep_logits<decltype(tag)::value, TS>(x, ct, cb, rs_p, q, k, ml, ch, nch == 1, j0, nkc);
+                fwd_sweep_logits<decltype(tag)::value, TS, T>(x, ct, cb, rs_p, q, k, ml, ch, nch == 1, j0, nkc);
             });
         }
 #ifndef CA_SKIP_SWEEP2
         for (int ch = 0; ch < nch; ch++) {  // sweep 2: out = sum p (v + Tv)
             const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0);
             dispatch_passes<NP>((nkc + 15) >> 4, [&](auto tag) {
-                fwd_sweep_values<decltype(tag)::value, TS>(x, ct, cb, rs_p, v, ml, out, ch, nch == 1, j0, nkc);
+                fwd_sweep_values<decltype(tag)::value, TS, T>(x, ct, cb, rs_p, v, ml, out, ch, nch == 1, j0, nkc);
             });
         }
 #endif
@@ -435,9 +457,9 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_
 // ------------------------------------------------------------------------------------------------
 // adds the key-side accumulators of pass t (lane (p, c): floats 4c..4c+3 of the key j0 + p * NPA + t) to grad[key, head, :]:
 // through a wave-private LDS tile, so that one atomic instruction covers four whole 64-byte head rows
-template <int NPA>
+template <int NPA, typename T>
 __device__ __forceinline__ void flush_key_pass(float *scr, float4 acc, rsrc_t rs_key, int j0, int t, int nkc, float *__restrict__ grad,
-                                               const LaneCtx &x) {
+                                               const LaneCtx<T> &x) {
     *reinterpret_cast<float4 *>(scr + x.p * 16 + 4 * x.c) = acc;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -453,14 +475,14 @@ __device__ __forceinline__ void flush_key_pass(float *scr, float4 acc, rsrc_t rs
 }
 
 // sweep A: grad_attn = <go, v + Tv>, gs = p (grad_attn - <go, out>) stored, dV += p go
-template <int NPA, int TS>
-__device__ __forceinline__ void bwd_sweep_values(const LaneCtx &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p, rsrc_t rs_g,
+template <int NPA, int TS, typename T>
+__device__ __forceinline__ void bwd_sweep_values(const LaneCtx<T> &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_p, rsrc_t rs_g,
                                                  float *scr, const float *__restrict__ go, const float *__restrict__ out,
-                                                 const float *__restrict__ v, float *__restrict__ grad_v, int j0, int nkc) {
+                                                 const T *__restrict__ v, float *__restrict__ grad_v, int j0, int nkc) {
     const int p = x.p, c = x.c;
     const int nvalid = min(max(nkc - p * NPA, 0), NPA);
     float4 v4[NPA], dv4[NPA];
-    load_key_rows<NPA>(x, cb, v, j0, v4);
+    load_key_rows<NPA, T>(x, cb, v, j0, v4);
 #pragma unroll
     for (int t = 0; t < NPA; t++) dv4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned w_nx[NPA];
@@ -488,11 +510,11 @@ __device__ __forceinline__ void bwd_sweep_values(const LaneCtx &x, const CellTas
         bload_floats<NPA>(rs_p, roff + ct.nk * 4, a_nx);
         const float delta = quad_sum(pdot4(go4, o4));  // = sum over the row of p * grad_attn
         float gs[NPA];
-        Rows3 rv = rows_at<2 * TS>(x.lds, row_off(w[0], x.L, c));
+        Rows3 rv = rows_at<2 * TS, T>(x.lds, row_off(w[0], x.L, c));
 #pragma unroll
         for (int t = 0; t < NPA; t++) {
             Rows3 rv1 = rv;
-            if (t + 1 < NPA) rv1 = rows_at<2 * TS>(x.lds, row_off(w[t + 1], x.L, c));
+            if (t + 1 < NPA) rv1 = rows_at<2 * TS, T>(x.lds, row_off(w[t + 1], x.L, c));
             const float ga = quad_sum(pdot4(go4, padd4(rsum(rv), v4[t])));
             gs[t] = a[t] * (ga - delta);
             dv4[t] = pfma4(a[t], go4, dv4[t]);
@@ -502,18 +524,18 @@ __device__ __forceinline__ void bwd_sweep_values(const LaneCtx &x, const CellTas
         if (c == 0) bstore_floats<NPA>(rs_g, roff, gs, nvalid);
     }
 #pragma unroll
-    for (int t = 0; t < NPA; t++) flush_key_pass<NPA>(scr, dv4[t], cb.key, j0, t, nkc, grad_v, x);
+    for (int t = 0; t < NPA; t++) flush_key_pass<NPA, T>(scr, dv4[t], cb.key, j0, t, nkc, grad_v, x);
 }
 
 // sweep B: dQ = sum gs (k + Tq), dK += gs (q + Tk)
-template <int NPA, int TS>
-__device__ __forceinline__ void bwd_sweep_keys(const LaneCtx &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_g, float *scr,
-                                               const float *__restrict__ q, const float *__restrict__ k, float *__restrict__ grad_q,
+template <int NPA, int TS, typename T>
+__device__ __forceinline__ void bwd_sweep_keys(const LaneCtx<T> &x, const CellTask &ct, const CellBufs &cb, rsrc_t rs_g, float *scr,
+                                               const T *__restrict__ q, const T *__restrict__ k, float *__restrict__ grad_q,
                                                float *__restrict__ grad_k, int ch, int j0, int nkc) {
     const int p = x.p, c = x.c;
     const int nvalid = min(max(nkc - p * NPA, 0), NPA);
     float4 k4[NPA], dk4[NPA];
-    load_key_rows<NPA>(x, cb, k, j0, k4);
+    load_key_rows<NPA, T>(x, cb, k, j0, k4);
 #pragma unroll
     for (int t = 0; t < NPA; t++) dk4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned w_nx[NPA];
@@ -522,7 +544,7 @@ __device__ __forceinline__ void bwd_sweep_keys(const LaneCtx &x, const CellTask 
     bload_floats<NPA>(rs_g, (j0 + p * NPA) * 4, g_nx);
     int ids = (int)bload_u32(cb.qid, x.lane * 4);
     int i_nx = __builtin_amdgcn_readlane(ids, 0);
-    float4 q_nx = ldg4(q + (size_t)i_nx * x.C + x.hoff);
+    float4 q_nx = ld_row4(q + (size_t)i_nx * x.C + x.hoff);
     for (int il = 0; il < ct.nq; il++) {
         const int i = i_nx;
         const int roff = (il * ct.nk + j0 + p * NPA) * 4;
@@ -536,19 +558,19 @@ __device__ __forceinline__ void bwd_sweep_keys(const LaneCtx &x, const CellTask 
         }
         if (((il + 1) & 63) == 0) ids = (int)bload_u32(cb.qid, (il + 1 + x.lane) * 4);
         i_nx = __builtin_amdgcn_readlane(ids, (il + 1) & 63);
-        q_nx = ldg4(q + (size_t)i_nx * x.C + x.hoff);
+        q_nx = ld_row4(q + (size_t)i_nx * x.C + x.hoff);
         bload_words<NPA>(cb.rel, roff + ct.nk * 4, w_nx);
         bload_floats<NPA>(rs_g, roff + ct.nk * 4, g_nx);
         float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
         RowOff ro = row_off(w[0], x.L, c);
-        Rows3 rq = rows_at<0>(x.lds, ro), rk = rows_at<TS>(x.lds, ro);
+        Rows3 rq = rows_at<0, T>(x.lds, ro), rk = rows_at<TS, T>(x.lds, ro);
 #pragma unroll
         for (int t = 0; t < NPA; t++) {
             Rows3 rq1 = rq, rk1 = rk;
             if (t + 1 < NPA) {
                 ro = row_off(w[t + 1], x.L, c);
-                rq1 = rows_at<0>(x.lds, ro);
-                rk1 = rows_at<TS>(x.lds, ro);
+                rq1 = rows_at<0, T>(x.lds, ro);
+                rk1 = rows_at<TS, T>(x.lds, ro);
             }
             dq = pfma4(g[t], padd4(rsum(rq), k4[t]), dq);
             dk4[t] = pfma4(g[t], padd4(rsum(rk), q4), dk4[t]);
@@ -563,20 +585,21 @@ __device__ __forceinline__ void bwd_sweep_keys(const LaneCtx &x, const CellTask 
         }
     }
 #pragma unroll
-    for (int t = 0; t < NPA; t++) flush_key_pass<NPA>(scr, dk4[t], cb.key, j0, t, nkc, grad_k, x);
+    for (int t = 0; t < NPA; t++) flush_key_pass<NPA, T>(scr, dk4[t], cb.key, j0, t, nkc, grad_k, x);
 }
 
-template <int NP, int LCAP>
+template <int NP, int LCAP, typename T>
 __global__ __launch_bounds__(CA_WAVES_BWD * 64) void cell_bwd_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ go,
-                                                                 const float *__restrict__ q, const float *__restrict__ k,
-                                                                 const float *__restrict__ v, const float *__restrict__ out,
-                                                                 const float *__restrict__ table_q, const float *__restrict__ table_k,
-                                                                 const float *__restrict__ table_v, const float *__restrict__ pbuf,
+                                                                 const T *__restrict__ q, const T *__restrict__ k,
+                                                                 const T *__restrict__ v, const float *__restrict__ out,
+                                                                 const T *__restrict__ table_q, const T *__restrict__ table_k,
+                                                                 const T *__restrict__ table_v, const float *__restrict__ pbuf,
                                                                  float *__restrict__ gsbuf, size_t plane, float *__restrict__ grad_q,
                                                                  float *__restrict__ grad_k, float *__restrict__ grad_v) {
     constexpr int D = 16, TS = TabGeo<LCAP>::TS;
-    extern __shared__ float lds[];
-    LaneCtx x;
+    extern __shared__ float lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
+    LaneCtx<T> x;
     x.lds = lds;
     x.L = L;
     x.h = h;
@@ -587,10 +610,10 @@ __global__ __launch_bounds__(CA_WAVES_BWD * 64) void cell_bwd_kernel(pointops2_c
     x.c = x.lane & 3;
     x.hoff = x.head * D + 4 * x.c;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *scr = lds + 3 * TS + wave * 256;
-    stage_table<D>(lds, table_q, L, h, x.head, 1);
-    stage_table<D>(lds + TS, table_k, L, h, x.head, 1);
-    stage_table<D>(lds + 2 * TS, table_v, L, h, x.head, 1);
+    float *scr = reinterpret_cast<float *>(lds + 3 * TS) + wave * 256;
+    stage_table_t<T>(lds, table_q, L, h, x.head);
+    stage_table_t<T>(lds + TS, table_k, L, h, x.head);
+    stage_table_t<T>(lds + 2 * TS, table_v, L, h, x.head);
     __syncthreads();
     const int nC = pl.counts[0];
     const float *pb = pbuf + (size_t)x.head * plane;
@@ -611,13 +634,13 @@ __global__ __launch_bounds__(CA_WAVES_BWD * 64) void cell_bwd_kernel(pointops2_c
         for (int ch = 0; ch < nch; ch++) {
             const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0);
             dispatch_passes<NP>((nkc + 15) >> 4, [&](auto tag) {
-                bwd_sweep_values<decltype(tag)::value, TS>(x, ct, cb, rs_p, rs_g, scr, go, out, v, grad_v, j0, nkc);
+                bwd_sweep_values<decltype(tag)::value, TS, T>(x, ct, cb, rs_p, rs_g, scr, go, out, v, grad_v, j0, nkc);
             });
         }
         for (int ch = 0; ch < nch; ch++) {
             const int j0 = ch * 16 * NP, nkc = min(16 * NP, ct.nk - j0);
             dispatch_passes<NP>((nkc + 15) >> 4, [&](auto tag) {
-                bwd_sweep_keys<decltype(tag)::value, TS>(x, ct, cb, rs_g, scr, q, k, grad_q, grad_k, ch, j0, nkc);
+                bwd_sweep_keys<decltype(tag)::value, TS, T>(x, ct, cb, rs_g, scr, q, k, grad_q, grad_k, ch, j0, nkc);
             });
         }
     }
@@ -665,9 +688,9 @@ struct CellTableGeo {
     static constexpr size_t lds_bytes() { return walk_bytes() > sum_bytes() ? walk_bytes() : sum_bytes(); }
 };
 
-template <int TA, bool BYKEY>
+template <int TA, bool BYKEY, typename XT>
 __global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ wbuf,
-                                                                        size_t plane, const float *__restrict__ X,
+                                                                        size_t plane, const XT *__restrict__ X,
                                                                         float *__restrict__ grad_table) {
     constexpr int D = 16;
     constexpr int MAXP = BYKEY ? 4 : 8;  // passes of 16 entries per row a segment holds in registers (a key's column is short)
@@ -764,7 +787,7 @@ __global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops
             }
         }
         int pt_n = (int)bload_u32(rs_row, kq * 4);
-        float xv_n = X[(size_t)pt_n * C + head * D + col];  // B operand: X[point of row r0 + kq, head, col]
+        float xv_n = ld_elem(X + (size_t)pt_n * C + head * D + col);  // B operand: X[point of row r0 + kq, head, col]
         pt_n = (int)bload_u32(rs_row, (4 + kq) * 4);
         for (int r0 = 0; r0 < nrows; r0 += 4) {
             unsigned wr[MAXP];
@@ -775,7 +798,7 @@ __global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops
                 wt[t] = wt_n[t];
             }
             const float xv = r0 + kq < nrows ? xv_n : 0.f;
-            xv_n = X[(size_t)pt_n * C + head * D + col];
+            xv_n = ld_elem(X + (size_t)pt_n * C + head * D + col);
             pt_n = (int)bload_u32(rs_row, (r0 + 8 + kq) * 4);
 #pragma unroll
             for (int t = 0; t < MAXP; t++)
@@ -819,15 +842,7 @@ __global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops
     }
 }
 
-static int device_cus() {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = kNumCU;
-        return n;
-    }();
-    return cus;
-}
+static int device_cus() { return num_cus(); }
 // persistent grid of the cell walkers: exactly the workgroups the chip holds at once (tasks are dealt to resident waves;
 // a workgroup that had to wait for a CU would start its share late), over all heads; never more waves than tasks
 template <typename K>
@@ -839,6 +854,64 @@ static int cell_grid_x(K kernel, size_t lds, int tasks, int h, int waves = CA_WA
     return max(1, min(cap, div_up(tasks, waves)));
 }
 
+template <typename T>
+static void launch_cell_fwd(const pointops2_cell_plan *plan, int h, int hdim, int L, const T *q, const T *k, const T *v, const T *table_q,
+                            const T *table_k, const T *table_v, float *out, float *ml, float *pbuf) {
+    if (plan == nullptr || plan->n_points <= 0) return;
+    if (hdim != 16) { set_error("cell_attention: d != 16"); return; }
+    if (L < 1) { set_error("cell_attention: no table rows"); return; }
+    const dim3 block(CA_WAVES * 64);
+    const size_t plane = (size_t)plan->n_pairs;
+    if (L <= 80) {
+        const size_t lds = TabGeo<80>::bytes(sizeof(T));
+        allow_big_lds(cell_fwd_kernel<CA_NP, 80, T>, lds);
+        const dim3 grid(cell_grid_x(cell_fwd_kernel<CA_NP, 80, T>, lds, plan->n_cells, h), h);
+        hipLaunchKernelGGL((cell_fwd_kernel<CA_NP, 80, T>), grid, block, lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out, ml,
+                           pbuf, plane);
+    } else if (L <= 160) {
+        const size_t lds = TabGeo<160>::bytes(sizeof(T));
+        allow_big_lds(cell_fwd_kernel<CA_NP, 160, T>, lds);
+        const dim3 grid(cell_grid_x(cell_fwd_kernel<CA_NP, 160, T>, lds, plan->n_cells, h), h);
+        hipLaunchKernelGGL((cell_fwd_kernel<CA_NP, 160, T>), grid, block, lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out, ml,
+                           pbuf, plane);
+    } else {
+        set_error("cell_attention: more than 160 table rows (use the operators)");
+        return;
+    }
+    check_launch();
+}
+
+template <typename T>
+static void launch_cell_bwd(const pointops2_cell_plan *plan, int h, int hdim, int L, const float *grad_out, const T *q, const T *k, const T *v,
+                            const float *out, const T *table_q, const T *table_k, const T *table_v, const float *pbuf, float *gsbuf, float *grad_q,
+                            float *grad_k, float *grad_v, float *grad_table_q, float *grad_table_k, float *grad_table_v) {
+    if (plan == nullptr || plan->n_points <= 0) return;
+    if (hdim != 16) { set_error("cell_attention: d != 16"); return; }
+    if (L < 1 || L > 80) { set_error("cell_attention backward: table rows L must be in 1..80"); return; }
+    hipStream_t st = state().stream;
+    const size_t lds = TabGeo<80>::bytes(sizeof(T)) + (size_t)CA_WAVES_BWD * 256 * sizeof(float);
+    allow_big_lds(cell_bwd_kernel<CA_NP_BWD, 80, T>, lds);
+    const size_t plane = (size_t)plan->n_pairs;
+    hipLaunchKernelGGL((cell_bwd_kernel<CA_NP_BWD, 80, T>), dim3(cell_grid_x(cell_bwd_kernel<CA_NP_BWD, 80, T>, lds, plan->n_cells, h, CA_WAVES_BWD), h),
+                       dim3(CA_WAVES_BWD * 64), lds, st, *plan, h, L, grad_out, q, k, v, out, table_q, table_k, table_v, pbuf, gsbuf, plane, grad_q,
+                       grad_k, grad_v);
+    // the three table gradients read p / gs only
+    const int gx_t = max(1, min(2 * device_cus() / max(h, 1), div_up(plan->n_cells, CT_WAVES)));
+    const dim3 tgrid(gx_t, h), tblock(CT_WAVES * 64);
+    if (L <= 64) {
+        using G = CellTableGeo<4>;
+        hipLaunchKernelGGL((cell_table_grad_kernel<4, false, T>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, q, grad_table_q);
+        hipLaunchKernelGGL((cell_table_grad_kernel<4, false, float>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, pbuf, plane, grad_out, grad_table_v);
+        hipLaunchKernelGGL((cell_table_grad_kernel<4, true, T>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, k, grad_table_k);
+    } else {
+        using G = CellTableGeo<5>;
+        hipLaunchKernelGGL((cell_table_grad_kernel<5, false, T>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, q, grad_table_q);
+        hipLaunchKernelGGL((cell_table_grad_kernel<5, false, float>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, pbuf, plane, grad_out, grad_table_v);
+        hipLaunchKernelGGL((cell_table_grad_kernel<5, true, T>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, k, grad_table_k);
+    }
+    check_launch();
+}
+
 }  // namespace p2
 
 using namespace p2;
@@ -848,60 +921,27 @@ extern "C" {
 void cell_attention_forward_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const float *q, const float *k,
                                      const float *v, const float *table_q, const float *table_k, const float *table_v, float *out,
                                      float *ml, float *pbuf) {
-    if (plan == nullptr || plan->n_points <= 0) return;
-    if (hdim != 16) { set_error("cell_attention: d != 16"); return; }
-    if (L < 1) { set_error("cell_attention: no table rows"); return; }
-    const dim3 block(CA_WAVES * 64);
-    const size_t plane = (size_t)plan->n_pairs;
-    if (L <= 80) {
-        const size_t lds = TabGeo<80>::bytes();
-        allow_big_lds(cell_fwd_kernel<CA_NP, 80>, lds);
-        const dim3 grid(cell_grid_x(cell_fwd_kernel<CA_NP, 80>, lds, plan->n_cells, h), h);
-        hipLaunchKernelGGL((cell_fwd_kernel<CA_NP, 80>), grid, block, lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out, ml,
-                           pbuf, plane);
-    } else if (L <= 160) {
-        const size_t lds = TabGeo<160>::bytes();
-        allow_big_lds(cell_fwd_kernel<CA_NP, 160>, lds);
-        const dim3 grid(cell_grid_x(cell_fwd_kernel<CA_NP, 160>, lds, plan->n_cells, h), h);
-        hipLaunchKernelGGL((cell_fwd_kernel<CA_NP, 160>), grid, block, lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out, ml,
-                           pbuf, plane);
-    } else {
-        set_error("cell_attention: more than 160 table rows (use the operators)");
-        return;
-    }
-    check_launch();
+    launch_cell_fwd<float>(plan, h, hdim, L, q, k, v, table_q, table_k, table_v, out, ml, pbuf);
 }
-
 void cell_attention_backward_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const float *grad_out, const float *q,
                                       const float *k, const float *v, const float *out, const float *table_q, const float *table_k,
                                       const float *table_v, const float *pbuf, float *gsbuf, float *grad_q, float *grad_k,
                                       float *grad_v, float *grad_table_q, float *grad_table_k, float *grad_table_v) {
-    if (plan == nullptr || plan->n_points <= 0) return;
-    if (hdim != 16) { set_error("cell_attention: d != 16"); return; }
-    if (L < 1 || L > 80) { set_error("cell_attention backward: table rows L must be in 1..80"); return; }
-    hipStream_t st = state().stream;
-    const size_t lds = TabGeo<80>::bytes() + (size_t)CA_WAVES_BWD * 256 * sizeof(float);
-    allow_big_lds(cell_bwd_kernel<CA_NP_BWD, 80>, lds);
-    const int N = plan->n_points;
-    const size_t plane = (size_t)plan->n_pairs;
-    hipLaunchKernelGGL((cell_bwd_kernel<CA_NP_BWD, 80>), dim3(cell_grid_x(cell_bwd_kernel<CA_NP_BWD, 80>, lds, plan->n_cells, h, CA_WAVES_BWD), h),
-                       dim3(CA_WAVES_BWD * 64), lds, st, *plan, h, L, grad_out, q, k, v, out, table_q, table_k, table_v, pbuf, gsbuf, plane, grad_q,
-                       grad_k, grad_v);
-    // the three table gradients read p / gs only
-    const int gx_t = max(1, min(2 * device_cus() / max(h, 1), div_up(plan->n_cells, CT_WAVES)));
-    const dim3 tgrid(gx_t, h), tblock(CT_WAVES * 64);
-    if (L <= 64) {
-        using G = CellTableGeo<4>;
-        hipLaunchKernelGGL((cell_table_grad_kernel<4, false>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, q, grad_table_q);
-        hipLaunchKernelGGL((cell_table_grad_kernel<4, false>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, pbuf, plane, grad_out, grad_table_v);
-        hipLaunchKernelGGL((cell_table_grad_kernel<4, true>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, k, grad_table_k);
-    } else {
-        using G = CellTableGeo<5>;
-        hipLaunchKernelGGL((cell_table_grad_kernel<5, false>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, q, grad_table_q);
-        hipLaunchKernelGGL((cell_table_grad_kernel<5, false>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, pbuf, plane, grad_out, grad_table_v);
-        hipLaunchKernelGGL((cell_table_grad_kernel<5, true>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, k, grad_table_k);
-    }
-    check_launch();
+    launch_cell_bwd<float>(plan, h, hdim, L, grad_out, q, k, v, out, table_q, table_k, table_v, pbuf, gsbuf, grad_q, grad_k, grad_v, grad_table_q,
+                           grad_table_k, grad_table_v);
+}
+// bf16 storage of q / k / v / tables (raw 16-bit patterns), fp32 arithmetic, fp32 outputs and gradients
+void cell_attention_forward_bf16_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const uint16_t *q, const uint16_t *k,
+                                          const uint16_t *v, const uint16_t *table_q, const uint16_t *table_k, const uint16_t *table_v,
+                                          float *out, float *ml, float *pbuf) {
+    launch_cell_fwd<bf16_t>(plan, h, hdim, L, q, k, v, table_q, table_k, table_v, out, ml, pbuf);
+}
+void cell_attention_backward_bf16_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const float *grad_out, const uint16_t *q,
+                                           const uint16_t *k, const uint16_t *v, const float *out, const uint16_t *table_q,
+                                           const uint16_t *table_k, const uint16_t *table_v, const float *pbuf, float *gsbuf, float *grad_q,
+                                           float *grad_k, float *grad_v, float *grad_table_q, float *grad_table_k, float *grad_table_v) {
+    launch_cell_bwd<bf16_t>(plan, h, hdim, L, grad_out, q, k, v, out, table_q, table_k, table_v, pbuf, gsbuf, grad_q, grad_k, grad_v, grad_table_q,
+                            grad_table_k, grad_table_v);
 }
 
 }  // extern "C"

@@ -83,7 +83,16 @@ class ForkJoin {
 };
 
 constexpr int WAVE = 64;
-constexpr int kNumCU = 256;  // MI355X
+constexpr int kNumCU = 256;  // MI355X (fallback when the device cannot be queried)
+// compute units of the current device, queried once (a partitioned device has fewer); sizes the persistent grids
+inline int num_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = kNumCU;
+        return n;
+    }();
+    return cus;
+}
 
 // Dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (gfx950: 160 KiB per CU).
 template <typename K>

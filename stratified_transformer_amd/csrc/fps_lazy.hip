@@ -32,12 +32,17 @@ namespace p2 {
 constexpr int LZ_NW = 16;
 constexpr int LZ_NT = LZ_NW * 64;
 constexpr int LZ_NBL = 2;                // owned buckets per lane: up to 2 * 64 * 16 = 2048 buckets of 64 points
-constexpr int LZ_CAP = 512;              // candidates / accepted samples per round
+constexpr int LZ_CAP = 1024;             // candidates / accepted samples per round
 constexpr int LZ_WORDS = LZ_CAP / 32;
-constexpr int LZ_TARGET = 352;           // candidates the threshold controller aims at
+constexpr int LZ_TARGET = 704;           // candidates the threshold controller aims at (at most)
 constexpr int LZ_MAXSB = LZ_NBL * 64;    // super-buckets: the 16 buckets (one per wave) with the same (slot, lane)
 constexpr int LZ_GRID = 1024;            // hash cells of the candidate grid
 constexpr int LZ_HITS = 8;               // listed hitters per candidate
+
+constexpr size_t lz_lds_bytes() {
+    return 16 * LZ_CAP + 8 * LZ_CAP + 8 * LZ_NW + 4 * LZ_CAP * 9 + 4 * LZ_GRID + 4 * LZ_MAXSB * LZ_WORDS + 4 * 2 * LZ_MAXSB + 4 * LZ_MAXSB * 6 + 4 * 2 * LZ_WORDS +
+           2 * LZ_CAP * LZ_HITS + 2 * LZ_CAP * 2 + LZ_CAP + 16 * 24;  // (+ alignment slack)
+}
 
 __device__ __forceinline__ unsigned ord_bits(float v) {  // order-preserving float -> unsigned
     const unsigned b = __float_as_uint(v);
@@ -71,22 +76,28 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     };
     if (STAMP) t_last = __builtin_amdgcn_s_memtime();
     constexpr int NW = LZ_NW, NT = LZ_NT, NBL = LZ_NBL, CAP = LZ_CAP, WORDS = LZ_WORDS;
-    __shared__ float cx[CAP], cy[CAP], cz[CAP], cd[CAP];  // candidates
-    __shared__ unsigned clo[CAP];
-    __shared__ unsigned long long skey[CAP];                // candidate keys, sorted descending (the reference's selection order)
-    __shared__ unsigned short sidx[CAP];                    // sorted position -> candidate slot
-    __shared__ unsigned ccell[CAP];                         // candidate's grid cell (10 bits per axis), by sorted position
-    __shared__ float4 sp4[CAP];                             // candidate (x, y, z, min-dist), by sorted position
-    __shared__ int ghead[LZ_GRID];                          // hash grid over the candidates: chains of sorted positions
-    __shared__ short gnext[CAP];
-    __shared__ unsigned short hl[CAP][LZ_HITS];             // hitters of a candidate (sorted positions, all with larger keys)
-    __shared__ unsigned char hcnt[CAP];                     // their number; > LZ_HITS: too many to list
-    __shared__ float ax[CAP], ay[CAP], az[CAP];            // accepted samples, in selection order
-    __shared__ unsigned sbhit[LZ_MAXSB][WORDS];            // accepted samples that may reach a super-bucket
-    __shared__ unsigned sbmax[2][LZ_MAXSB];                // largest min-dist (bits) inside a super-bucket, double-buffered
-    __shared__ unsigned sbbox[LZ_MAXSB][6];                // super-bucket boxes (ord_bits)
-    __shared__ unsigned accw[2][WORDS];
-    __shared__ unsigned long long wkey[NW];
+    // LDS: carved from one dynamic block (more than the 64 KiB a kernel may declare statically)
+    extern __shared__ unsigned char lz_lds[];
+    unsigned char *lp = lz_lds;
+    auto carve = [&](size_t bytes) { unsigned char *r = lp; lp += (bytes + 15) & ~(size_t)15; return r; };
+    float4 *sp4 = reinterpret_cast<float4 *>(carve(sizeof(float4) * CAP));                 // candidate (x, y, z, min-dist), by sorted position
+    unsigned long long *skey = reinterpret_cast<unsigned long long *>(carve(8 * CAP));     // candidate keys, sorted descending (the reference's selection order)
+    unsigned long long *wkey = reinterpret_cast<unsigned long long *>(carve(8 * NW));
+    float *cx = reinterpret_cast<float *>(carve(4 * CAP)), *cy = reinterpret_cast<float *>(carve(4 * CAP));  // candidates, in gather order
+    float *cz = reinterpret_cast<float *>(carve(4 * CAP)), *cd = reinterpret_cast<float *>(carve(4 * CAP));
+    unsigned *clo = reinterpret_cast<unsigned *>(carve(4 * CAP));
+    unsigned *ccell = reinterpret_cast<unsigned *>(carve(4 * CAP));                        // candidate's grid cell (10 bits per axis), by sorted position
+    int *ghead = reinterpret_cast<int *>(carve(4 * LZ_GRID));                              // hash grid over the candidates: chains of sorted positions
+    float *ax = reinterpret_cast<float *>(carve(4 * CAP)), *ay = reinterpret_cast<float *>(carve(4 * CAP));  // accepted samples, in selection order
+    float *az = reinterpret_cast<float *>(carve(4 * CAP));
+    unsigned (*sbhit)[WORDS] = reinterpret_cast<unsigned (*)[WORDS]>(carve(4 * LZ_MAXSB * WORDS));  // accepted samples that may reach a super-bucket
+    unsigned (*sbmax)[LZ_MAXSB] = reinterpret_cast<unsigned (*)[LZ_MAXSB]>(carve(4 * 2 * LZ_MAXSB));  // largest min-dist (bits) inside a super-bucket, double-buffered
+    unsigned (*sbbox)[6] = reinterpret_cast<unsigned (*)[6]>(carve(4 * LZ_MAXSB * 6));     // super-bucket boxes (ord_bits)
+    unsigned (*accw)[WORDS] = reinterpret_cast<unsigned (*)[WORDS]>(carve(4 * 2 * WORDS));
+    unsigned short (*hl)[LZ_HITS] = reinterpret_cast<unsigned short (*)[LZ_HITS]>(carve(2 * CAP * LZ_HITS));  // hitters of a candidate (sorted positions, all with larger keys)
+    unsigned short *sidx = reinterpret_cast<unsigned short *>(carve(2 * CAP));             // sorted position -> candidate slot
+    short *gnext = reinterpret_cast<short *>(carve(2 * CAP));
+    unsigned char *hcnt = carve(CAP);                                                      // number of hitters; > LZ_HITS: too many to list
     __shared__ unsigned long long s_tover, s_tdrop;
     __shared__ int s_cnt, s_nacc, s_changed[2];
     __shared__ unsigned s_org[3];                           // cloud origin (ord_bits of the bounding box minimum)
@@ -514,11 +525,13 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
 
 void fps_lazy_launch(int b, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset, float4 *pts, const unsigned *rank,
                      const int *prev_idx, const int *prev_offset, const int *verified, int *idx, hipStream_t st) {
+    allow_big_lds(fps_lazy_kernel<false>, lz_lds_bytes());
+    allow_big_lds(fps_lazy_kernel<true>, lz_lds_bytes());
     if (getenv("P2_FPS_STAMPS")) {  // diagnostic only: synchronous, prints the phase cycles of wave 0 to stderr
         unsigned long long *dbg = nullptr, host[12];
         (void)hipMalloc(&dbg, sizeof(host) * b);
         (void)hipMemset(dbg, 0, sizeof(host) * b);
-        hipLaunchKernelGGL(fps_lazy_kernel<true>, dim3(b), dim3(LZ_NT), 0, st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
+        hipLaunchKernelGGL(fps_lazy_kernel<true>, dim3(b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
                            verified, idx, dbg);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
@@ -528,7 +541,7 @@ void fps_lazy_launch(int b, int Bref, int log2B, const float *xyz, const int *of
                 host[9]);
         return;
     }
-    hipLaunchKernelGGL(fps_lazy_kernel<false>, dim3(b), dim3(LZ_NT), 0, st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
+    hipLaunchKernelGGL(fps_lazy_kernel<false>, dim3(b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
                        verified, idx, (unsigned long long *)nullptr);
 }
 

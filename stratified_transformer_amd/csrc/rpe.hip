@@ -556,8 +556,8 @@ static int table_rows_or_error() {
 // waves_per_block: rows a workgroup handles at a time; per_cu: resident workgroups per CU (LDS / register budget)
 static int persistent_blocks(int rows, int head_groups, int waves_per_block = 4, int per_cu = 2) {
     int want = div_up(rows, waves_per_block);
-    int cap = kNumCU * per_cu;
-    if (head_groups > 1) cap = max(kNumCU * per_cu / head_groups, kNumCU / 2);
+    int cap = num_cus() * per_cu;
+    if (head_groups > 1) cap = max(num_cus() * per_cu / head_groups, num_cus() / 2);
     return min(want, cap);
 }
 
@@ -595,8 +595,12 @@ void dot_prod_with_idx_forward_cuda_launcher_v3(int N, int M, int h, int hdim, i
                                                 float *output) {
     (void)n_max;
     if (N <= 0 || M <= 0) return;
-    const int L = table_rows_or_error();
-    if (L <= 0) return;
+    const int L = state().table_rows;
+    if (L <= 0) {  // table length not announced: the generic global-memory kernels (rpe_fallback.hip)
+        a2_fwd_global(N, M, h, hdim, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output);
+        check_launch();
+        return;
+    }
     hipStream_t st = state().stream;
     if (hdim == 16) P2_LAUNCH_HG(16, 2, {
         allow_big_lds(a2_fwd_kernel<Dc, HGc>, lds_bytes);
@@ -654,8 +658,12 @@ void dot_prod_with_idx_backward_cuda_launcher_v3(int N, int M, int h, int hdim, 
                                                  float *grad_table_q, float *grad_table_k) {
     (void)n_max;
     if (N <= 0 || M <= 0) return;
-    const int L = table_rows_or_error();
-    if (L <= 0) return;
+    const int L = state().table_rows;
+    if (L <= 0) {
+        a2_bwd_global(N, M, h, hdim, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, grad_q, grad_k, grad_table_q, grad_table_k);
+        check_launch();
+        return;
+    }
     hipStream_t st = state().stream;
     const LaunchState &ls = state();
     const int *co = ls.csc_offsets, *cp = ls.csc_pair;
@@ -698,8 +706,12 @@ void attention_step2_with_rel_pos_value_forward_cuda_launcher_v2(int N, int M, i
                                                                  const float *table, const int *rel_idx, float *output) {
     (void)n_max;
     if (N <= 0 || M <= 0) return;
-    const int L = table_rows_or_error();
-    if (L <= 0) return;
+    const int L = state().table_rows;
+    if (L <= 0) {
+        a4_fwd_global(N, M, h, hdim, attn, v, index0_offsets, index1, table, rel_idx, output);
+        check_launch();
+        return;
+    }
     hipStream_t st = state().stream;
     if (hdim == 16) P2_LAUNCH_HG(16, 1, {
         allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
@@ -722,8 +734,12 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
                                                                   float *grad_attn, float *grad_v, float *grad_table) {
     (void)n_max;
     if (N <= 0 || M <= 0) return;
-    const int L = table_rows_or_error();
-    if (L <= 0) return;
+    const int L = state().table_rows;
+    if (L <= 0) {
+        a4_bwd_global(N, M, h, hdim, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_v, grad_table);
+        check_launch();
+        return;
+    }
     hipStream_t st = state().stream;
     const LaunchState &ls = state();
     const int *co = ls.csc_offsets, *cp = ls.csc_pair, *cq = ls.csc_query;

@@ -580,8 +580,8 @@ __global__ __launch_bounds__(512, 4) void wattn_bwd_key_kernel(int NK, int h, in
 // ---- launchers -------------------------------------------------------------------------------------------
 static int walk_blocks(int rows, int groups, int waves_per_block, int per_cu) {
     int want = div_up(rows, waves_per_block);
-    int cap = kNumCU * per_cu;
-    if (groups > 1) cap = max(kNumCU * per_cu / groups, kNumCU / 2);
+    int cap = num_cus() * per_cu;
+    if (groups > 1) cap = max(num_cus() * per_cu / groups, num_cus() / 2);
     return max(1, min(want, cap));
 }
 

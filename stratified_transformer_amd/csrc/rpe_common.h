@@ -83,6 +83,16 @@ __device__ __forceinline__ PairIds load_pair_ids(const int *__restrict__ idx1, c
     return r;
 }
 
+// rpe_fallback.hip: the rel-pos operators without a table length (global-memory tables, the reference's atomics)
+void a2_fwd_global(int N, int M, int h, int d, const float *q, const int *offs, const float *k, const int *idxk, const float *tq,
+                   const float *tk, const int *rel, float *out);
+void a2_bwd_global(int N, int M, int h, int d, const float *go, const float *q, const int *offs, const float *k, const int *idxk,
+                   const float *tq, const float *tk, const int *rel, float *gq, float *gk, float *gtq, float *gtk);
+void a4_fwd_global(int N, int M, int h, int d, const float *attn, const float *v, const int *offs, const int *idx1, const float *tv,
+                   const int *rel, float *out);
+void a4_bwd_global(int N, int M, int h, int d, const float *go, const int *offs, const int *idx1, const float *attn, const float *v,
+                   const float *tv, const int *rel, float *ga, float *gv, float *gt);
+
 // rpe_bwd_mfma.hip
 bool a2_bwd_mfma(int N, int NK, int M, int h, int hdim, int L, const float *go, const float *q, const int *offs, const float *k,
                  const float *table_q, const float *table_k, const int *rel, const int *co, const int *cp,

@@ -111,14 +111,16 @@ class CellAttention(Function):
             raise RuntimeError("cell_attention: the plan was built for %d points, q/k/v have %d/%d/%d rows" % (plan.n_points, N, k.shape[0], v.shape[0]))
         if L > plan.table_rows:
             raise RuntimeError("cell_attention: the plan's rel-pos indices were clamped to %d rows, the tables have %d" % (plan.table_rows, L))
-        pointops_cuda._chk((q, torch.float32, "q"), (k, torch.float32, "k"), (v, torch.float32, "v"),
-                           (table_q, torch.float32, "table_q"), (table_k, torch.float32, "table_k"), (table_v, torch.float32, "table_v"))
+        st = q.dtype  # storage type of q / k / v / tables: fp32, or bf16 (fp32 arithmetic and outputs either way)
+        if st not in (torch.float32, torch.bfloat16):
+            raise TypeError("cell_attention: q / k / v / tables must all be float32 or all bfloat16, got %s" % st)
+        pointops_cuda._chk((q, st, "q"), (k, st, "k"), (v, st, "v"), (table_q, st, "table_q"), (table_k, st, "table_k"), (table_v, st, "table_v"))
         assert table_k.shape == table_q.shape and table_v.shape == table_q.shape
         dev = q.device
         out = torch.empty((N, h, hdim), dtype=torch.float32, device=dev)
         ml = torch.empty((N, h, 2), dtype=torch.float32, device=dev)
         pbuf = torch.empty((h, max(plan.n_pairs, 1)), dtype=torch.float32, device=dev)
-        _lib.call("cell_attention_forward_launcher", plan.c_arg(), h, hdim, L, ptr(q), ptr(k), ptr(v), ptr(table_q), ptr(table_k), ptr(table_v),
+        _lib.call("cell_attention_forward_launcher" if st == torch.float32 else "cell_attention_forward_bf16_launcher", plan.c_arg(), h, hdim, L, ptr(q), ptr(k), ptr(v), ptr(table_q), ptr(table_k), ptr(table_v),
                   ptr(out), ptr(ml), ptr(pbuf), device=dev)
         ctx.plan = plan
         ctx.save_for_backward(q, k, v, table_q, table_k, table_v, out, pbuf)
@@ -134,12 +136,15 @@ class CellAttention(Function):
         grad_out = grad_out.contiguous()
         pointops_cuda._chk((grad_out, torch.float32, "grad_out"))
         gsbuf = torch.empty_like(pbuf)
-        grad_q = torch.empty_like(q)
-        grad_k, grad_v = torch.zeros_like(k), torch.zeros_like(v)
-        gtq, gtk, gtv = torch.zeros_like(table_q), torch.zeros_like(table_k), torch.zeros_like(table_v)
-        _lib.call("cell_attention_backward_launcher", plan.c_arg(), h, hdim, L, ptr(grad_out), ptr(q), ptr(k), ptr(v), ptr(out), ptr(table_q),
+        f32 = dict(dtype=torch.float32, device=dev)
+        grad_q = torch.empty(q.shape, **f32)
+        grad_k, grad_v = torch.zeros(k.shape, **f32), torch.zeros(v.shape, **f32)
+        gtq, gtk, gtv = torch.zeros(table_q.shape, **f32), torch.zeros(table_k.shape, **f32), torch.zeros(table_v.shape, **f32)
+        _lib.call("cell_attention_backward_launcher" if q.dtype == torch.float32 else "cell_attention_backward_bf16_launcher", plan.c_arg(), h, hdim, L, ptr(grad_out), ptr(q), ptr(k), ptr(v), ptr(out), ptr(table_q),
                   ptr(table_k), ptr(table_v), ptr(pbuf), ptr(gsbuf), ptr(grad_q), ptr(grad_k), ptr(grad_v), ptr(gtq), ptr(gtk), ptr(gtv),
                   device=dev)
+        if q.dtype != torch.float32:  # autograd wants a gradient of the operand's dtype; the sums above were taken in fp32
+            grad_q, grad_k, grad_v, gtq, gtk, gtv = (g.to(q.dtype) for g in (grad_q, grad_k, grad_v, gtq, gtk, gtv))
         return grad_q, grad_k, grad_v, gtq, gtk, gtv, None
 
 

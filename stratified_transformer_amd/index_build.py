@@ -243,31 +243,23 @@ def cell_query_cap(n_points, heads):
     return cap
 
 
-def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_table_rows=None, cell_max_queries=0):
-    """Even and odd block index of one stage, built by the HIP kernels of csrc/index.hip.
-
-    xyz [N,3] f32 (GPU), offset [b] i32, downsample_idx [m] i32 -> (BlockIndex even, BlockIndex odd),
-    bit-identical to build_block_index() on the same inputs.  cell_table_rows = L: also the cell plan of both
-    patterns (BlockIndex.cells) for fused.cell_attention, with the rel-pos indices clamped to [0, L); cell_max_queries > 0
-    cuts cells into pieces of at most that many queries (cell_query_cap)."""
+def stage_partitions_hip(xyz, offset, window_size):
+    """The part of a stage's index build that needs the coordinates only: bounding box and the four window partitions
+    (grid_sample x 4, stratified_transformer.py:277,280,297,300).  One host sync (the box sizes the sort keys).  Returns the
+    context stage_index_hip continues from - a caller can run this beside the stage's FPS instead of behind it."""
     import numpy as np
     from . import _lib
     from ._lib import ptr
     assert xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous()
     N, b, dev = xyz.shape[0], offset.shape[0], xyz.device
-    m = int(downsample_idx.shape[0])
     l = _lib.lib()
     w32 = np.float32(window_size)
     i32 = dict(dtype=torch.int32, device=dev)
-
-    def call(name, *args):
-        _lib.call(name, *args, device=dev)
-
     with torch.cuda.device(dev):
         ws_bytes = int(l.pointops2_index_workspace_bytes(N))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         bbox = torch.empty(6, dtype=torch.float32, device=dev)
-        call("pointops2_bbox_launcher", N, ptr(xyz), ptr(bbox))
+        _lib.call("pointops2_bbox_launcher", N, ptr(xyz), ptr(bbox), device=dev)
         bb = np.asarray(bbox.tolist(), dtype=np.float32)   # host sync 1: sizes the radix-sort key
         parts = {}
         for name, size, shift in (("small", w32, np.float32(0)), ("small_shift", w32, np.float32(0.5) * w32),
@@ -277,9 +269,35 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
                 nvox *= int((np.float32(bb[3 + a] + shift) - bb[a]) / size) + 1
             key_bits = max(int(nvox * b).bit_length() + 1, 8)
             part = HipPartition(torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N + 2, **i32), torch.empty(1, **i32))
-            call("pointops2_window_partition_launcher", N, b, ptr(xyz), ptr(offset), ptr(bbox), float(size), float(shift), key_bits,
-                 ptr(part.cluster), ptr(part.order), ptr(part.starts), ptr(part.n_windows), ptr(ws), ws_bytes)
+            _lib.call("pointops2_window_partition_launcher", N, b, ptr(xyz), ptr(offset), ptr(bbox), float(size), float(shift), key_bits,
+                      ptr(part.cluster), ptr(part.order), ptr(part.starts), ptr(part.n_windows), ptr(ws), ws_bytes, device=dev)
             parts[name] = part
+    return dict(parts=parts, ws=ws, ws_bytes=ws_bytes, bbox=bbox, w32=w32)
+
+
+def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_table_rows=None, cell_max_queries=0, partitions=None):
+    """Even and odd block index of one stage, built by the HIP kernels of csrc/index.hip.
+
+    xyz [N,3] f32 (GPU), offset [b] i32, downsample_idx [m] i32 -> (BlockIndex even, BlockIndex odd),
+    bit-identical to build_block_index() on the same inputs.  cell_table_rows = L: also the cell plan of both
+    patterns (BlockIndex.cells) for fused.cell_attention, with the rel-pos indices clamped to [0, L); cell_max_queries > 0
+    cuts cells into pieces of at most that many queries (cell_query_cap).  partitions: the result of stage_partitions_hip
+    on the same xyz / offset / window_size, when the caller has already run it."""
+    import numpy as np
+    from . import _lib
+    from ._lib import ptr
+    assert xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous()
+    N, b, dev = xyz.shape[0], offset.shape[0], xyz.device
+    m = int(downsample_idx.shape[0])
+    l = _lib.lib()
+    i32 = dict(dtype=torch.int32, device=dev)
+
+    def call(name, *args):
+        _lib.call(name, *args, device=dev)
+
+    ctx = partitions if partitions is not None else stage_partitions_hip(xyz, offset, window_size)
+    parts, ws, ws_bytes, bbox, w32 = ctx["parts"], ctx["ws"], ctx["ws_bytes"], ctx["bbox"], ctx["w32"]
+    with torch.cuda.device(dev):
         sampled = torch.zeros(N, **i32)
         out = []
         pending = []
@@ -329,3 +347,30 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
                 plan = CellPlan(N, n_cells, P, K, nk_max, int(cell_table_rows), n_parents, cell_keys=cell_keys, kcell=kcell, relp=relp, **cells)
             out.append(BlockIndex(index_0, index_1, offsets, counts.max(), rel, None, plan))
     return out[0], out[1], parts
+
+
+# ---------------------------------------------------------------------------------------------
+# Swin3D variant (model/swin3d_transformer.py): the same three operators on dense window pairs, tables of
+# 2*int(window/quant) - 1 rows, rel-pos index = difference of the points' quantised in-window coordinates
+# ---------------------------------------------------------------------------------------------
+def swin_table_rows(window_size, quant_size):
+    return 2 * int(window_size / quant_size) - 1  # swin3d_transformer.py:109-117
+
+
+def swin_rel_pos_index(xyz, index_0, index_1, window_size, quant_size, shift):
+    """swin3d_transformer.py:151-154 + map_func :129-130 with torch ops on the tensors' device (what the model file itself runs)"""
+    qgl = int(window_size / quant_size)
+    xyz_quant = (xyz - xyz.min(0)[0] + shift) % window_size
+    xyz_quant = xyz_quant // quant_size
+    return (xyz_quant[index_0.long()] - xyz_quant[index_1.long()] + qgl - 1).int()
+
+
+def swin_stage_index_hip(xyz, offset, window_size, quant_size):
+    """Plain and shifted block index of one Swin3D stage (swin3d_transformer.py:239-278) from the HIP index build: the dense
+    pairs of the small-window partitions (a Stratified stage without sampled keys), then the Swin rel-pos index."""
+    none = torch.empty(0, dtype=torch.int32, device=xyz.device)
+    even, odd, parts = stage_index_hip(xyz, offset, window_size, quant_size, none)
+    ws = torch.tensor([window_size] * 3).type_as(xyz)
+    for blk, shift in ((even, 0.0), (odd, 1 / 2 * ws)):
+        blk.rel_idx = swin_rel_pos_index(xyz, blk.index_0, blk.index_1, window_size, quant_size, shift).contiguous()
+    return even, odd, parts

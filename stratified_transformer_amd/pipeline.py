@@ -269,6 +269,9 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         n_off_host, n_offset = plan_host[level[0]], plan_dev[level[0]]
         idx = timer.run("fps/transition", P.furthestsampling, x, off, n_offset)
         n_xyz = x[idx.long(), :].contiguous()
+        ready = torch.cuda.Event()
+        ready.record(geo)
+        cloud_ready[level[0]] = ready
         if overlap:  # the grouping query leaves the sampling chain here
             knn_s.wait_stream(geo)
             for t in (x, n_xyz, off, n_offset):
@@ -277,6 +280,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
             knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, x, n_xyz, off, n_offset)
         return n_xyz, n_offset, n_off_host, knn_idx
 
+    cloud_ready = {}  # transition level -> event: the level's point cloud exists (recorded on the geometry stream)
     cur_xyz, cur_off, cur_off_host = xyz, offset, offset_host
     if not cfg.stem_transformer:  # Stratified.forward :458-462: a TransitionDown precedes the first attention stage
         with on_geo():
@@ -309,14 +313,23 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         ds, ev_ds, _ = geo_out[si]
         st = cfg.stages[si]
         if overlap:
-            idx_s.wait_event(ev_ds)
             for t in (ds, x, off):
                 t.record_stream(idx_s)
         with torch.cuda.stream(idx_s):
+            parts_ctx = None
+            if use_hip_index:
+                # the window partitions need the coordinates only: they run BESIDE the stage's sampling (which the pair
+                # lists below have to wait for), not behind it
+                lvl = si - first + (0 if cfg.stem_transformer else 1)
+                if overlap and lvl in cloud_ready:
+                    idx_s.wait_event(cloud_ready[lvl])
+                parts_ctx = timer.run("index/partitions", index_build.stage_partitions_hip, x, off, st.window_size)
+            if overlap:
+                idx_s.wait_event(ev_ds)
             if use_hip_index:
                 even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds,
                                          table_rows(st) if (cells or (fused == "cell" and not shard)) else None,
-                                         index_build.cell_query_cap(x.shape[0], st.num_heads))
+                                         index_build.cell_query_cap(x.shape[0], st.num_heads), parts_ctx)
             else:
                 parts = timer.run("index/partition", index_build.stage_partitions, x, off, st.window_size)
                 even = timer.run("index/pairs", index_build.build_block_index, x, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)

@@ -212,3 +212,44 @@ def test_knn_fewer_points_than_k():
     # unfilled heap slots keep (1e10, start) and sort last (knnquery_cuda_kernel.cu:88-91,103)
     assert idx[0].tolist() == [0, 1, 2, 0, 0]
     np.testing.assert_allclose(dist[0], [0, 1, 2, 1e5, 1e5])
+
+
+# ---- Swin3D variant: the oracle's restatement against vectors produced by model/swin3d_transformer.py ----
+def test_swin3d_oracle_index_matches_reference_golden():
+    import os
+    from oracle import index_ref
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "swin3d_window_attention.npz"))
+    xyz = torch.from_numpy(g["xyz"])
+    for pat in (0, 1):
+        got = index_ref.swin_stage_indices(xyz, g["offset"], float(g["window_size"]), float(g["quant_size"]), pat)
+        assert np.array_equal(got["index_0"].numpy(), g[f"p{pat}_index_0"].astype(np.int64))
+        assert np.array_equal(got["index_1"].numpy(), g[f"p{pat}_index_1"].astype(np.int64))
+        assert np.array_equal(got["offsets"].numpy(), g[f"p{pat}_offsets"].astype(np.int64))
+        assert got["n_max"] == int(g[f"p{pat}_n_max"])
+        assert np.array_equal(got["rel_idx"].numpy(), g[f"p{pat}_rel_idx_cpu"].astype(np.int32))
+        assert got["rel_idx"].min() >= 0 and got["rel_idx"].max() <= 30
+
+
+def test_stratified_h6_L80_oracle_matches_reference_golden():
+    """second fixture of the reference's WindowAttention: 4 000 points (BASELINE config-1 size), h = 6, L = 80"""
+    import os
+    from oracle import index_ref, pointops_ref as ref
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "window_attention_4000_h6.npz"))
+    xyz = torch.from_numpy(g["xyz"])
+    w, quant = float(g["window_size"]), float(g["quant_size"])
+    got = index_ref.build_stage_indices(xyz, g["offset"], w, quant, torch.from_numpy(g["downsample_idx"].astype(np.int32)), 0, div_mode="cpu")
+    assert np.array_equal(got["index_0"].numpy(), g["index_0"].astype(np.int64))
+    assert np.array_equal(got["index_1"].numpy(), g["index_1"].astype(np.int64))
+    assert np.array_equal(got["offsets"].numpy(), g["offsets"].astype(np.int64))
+    assert np.array_equal(got["rel_idx"].numpy(), g["rel_idx_cpu"].astype(np.int32))
+    # the module through the oracle's kernels: qkv Linear, A1, A2, softmax, A4, proj
+    N, C = g["feats"].shape
+    h = g["table_q"].shape[1]
+    qkv = (g["feats"] @ g["qkv_weight"].T + g["qkv_bias"]).reshape(N, 3, h, C // h).transpose(1, 0, 2, 3)
+    q, k, v = (np.ascontiguousarray(qkv[i], dtype=np.float32) for i in range(3))
+    q = q * np.float32((C // h) ** -0.5)
+    i1, offs, rel = g["index_1"].astype(np.int32), g["offsets"].astype(np.int32), g["rel_idx_cpu"].astype(np.int32)
+    sm = ref.segment_softmax(ref.attention_step1_v2(q, k, i1, offs) + ref.dot_prod_with_idx_v3(q, offs, k, i1, g["table_q"], g["table_k"], rel), offs)
+    x = ref.attention_step2_with_rel_pos_value_v2(sm, v, offs, i1, g["table_v"], rel)
+    y = x.reshape(N, C) @ g["proj_weight"].T + g["proj_bias"]
+    np.testing.assert_allclose(y, g["out"], rtol=1e-4, atol=1e-4)

@@ -23,6 +23,10 @@ def group_of(name):
         return "fps"
     if name.startswith("knn_"):
         return "knn"
+    if name.startswith("cell_fwd_kernel"):
+        return "cell_attn_fwd"
+    if name.startswith("cell_bwd_kernel") or name.startswith("cell_table_grad_kernel"):
+        return "cell_attn_bwd"
     for k in ("a1_fwd", "a2_fwd", "a4_fwd", "seg_softmax_fwd"):
         if name.startswith(k):
             return "attn_fwd"
@@ -34,15 +38,25 @@ def group_of(name):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 blocks_per_pass = int(sys.argv[4]) if len(sys.argv) > 4 else 12  # attention blocks of the config (s3dis: 2+2+6+2)
-steps = max(1, fetch.get("a1_fwd_kernel<16>", [blocks_per_pass, 0])[0] // blocks_per_pass)
+def launches(prefix):
+    return sum(v[0] for k, v in fetch.items() if k.startswith(prefix))
+
+
+# passes of each kind in the profiled process: the operator path launches a1_fwd once per block, the cell module cell_fwd_kernel;
+# every pass of either kind launches the grid kNN six times
+ops_passes = max(1, launches("a1_fwd_kernel") // blocks_per_pass)
+cell_passes = max(1, launches("cell_fwd_kernel") // blocks_per_pass)
+all_passes = max(1, launches("knn_grid_kernel") // 6)
+steps = all_passes
+per = {"attn_fwd": ops_passes, "attn_bwd": ops_passes, "cell_attn_fwd": cell_passes, "cell_attn_bwd": cell_passes}
 kernels, groups = {}, collections.defaultdict(float)
 for name in sorted(set(fetch) | set(write)):
     n = max(fetch.get(name, [0, 0])[0], write.get(name, [0, 0])[0])
     rd = 2.0 * fetch.get(name, [0, 0.0])[1] * 1024.0
     wr = write.get(name, [0, 0.0])[1] * 1024.0
     kernels[name] = dict(launches=n, read_bytes_per_launch=rd / max(n, 1), write_bytes_per_launch=wr / max(n, 1))
-    groups[group_of(name)] += (rd + wr) / steps
-out = dict(passes_profiled=steps, note="bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, summed over the kernels of a group, per scene pass",
+    groups[group_of(name)] += (rd + wr) / per.get(group_of(name), all_passes)
+out = dict(passes_profiled=dict(all=all_passes, operator_api=ops_passes, cell=cell_passes), note="bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, summed over the kernels of a group, per scene pass",
            bytes_per_pass_by_group=dict(groups), kernels=kernels)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["bytes_per_pass_by_group"], indent=1), "passes", steps)

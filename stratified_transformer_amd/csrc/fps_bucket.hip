@@ -695,6 +695,7 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     int *inv = (int *)p; p += f4;                                   // original index -> sampler order (persistent)
     unsigned long long *thr = (unsigned long long *)p; p += f8;    // verification thresholds
     int *first_bad = (int *)p; p += al((size_t)b * 4);
+    void *xchg = p; p += al((size_t)b * LZ_XCHG);                  // where the round sampler's workgroups meet (fps_lazy.hip)
     void *cub_tmp = p;
     size_t cub_bytes = w.bytes - (size_t)(p - reinterpret_cast<char *>(w.ptr));
     FpsResume rs = fps_resume();
@@ -725,7 +726,7 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     // round-based sampler (fps_lazy.hip) on the same state; P2_FPS_STEPWISE=1 keeps the step-by-step kernel below
     static const bool stepwise = getenv("P2_FPS_STEPWISE") != nullptr;
     if (BSZ == 64 && !stepwise) {
-        fps_lazy_launch(b, Bref, log2B, xyz, offset, new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, st);
+        fps_lazy_launch(b, n, Bref, log2B, xyz, offset, new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, xchg, st);
         return true;
     }
     static const int nw_env = getenv("P2_FPS_WAVES") ? atoi(getenv("P2_FPS_WAVES")) : 0;
@@ -786,7 +787,7 @@ void pointops2_set_workspace(void *ptr, size_t bytes) {
 
 size_t pointops2_fps_workspace_bytes(int b, int N) {
     if (b <= 0 || N <= 0) return 0;
-    return al((size_t)N * 16) + 4 * al((size_t)N * 4) + 3 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al((size_t)b * 4) + al(fps_cub_bytes(b, N));
+    return al((size_t)N * 16) + 4 * al((size_t)N * 4) + 3 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al((size_t)b * 4) + al((size_t)b * LZ_XCHG) + al(fps_cub_bytes(b, N));
 }
 
 void pointops2_set_fps_resume(const int *prev_idx, const int *prev_offset) {

@@ -47,8 +47,12 @@ __device__ __forceinline__ float rl(float v, int lane) {  // value of a wave-uni
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// fps_lazy.hip: the round-based sampler on the state fps_bucket_launch prepares; same arguments as fps_bucket_kernel
-void fps_lazy_launch(int b, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset, float4 *pts, const unsigned *rank,
-                     const int *prev_idx, const int *prev_offset, const int *verified, int *idx, hipStream_t st);
+// fps_lazy.hip: the round-based sampler on the state fps_bucket_launch prepares; same arguments as fps_bucket_kernel plus the
+// exchange area its workgroups meet in (b * LZ_XCHG bytes of the workspace) and the largest cloud of the batch
+constexpr int LZ_CAP = 512;    // candidates / accepted samples per round (1024 / 704: fewer rounds, each dearer: 14.3 ms against 12.3)
+constexpr int LZ_GMAX = 8;     // workgroups per batch element, at most
+constexpr size_t LZ_XCHG = 64 + 2 * LZ_GMAX * 32 + 2 * LZ_GMAX * LZ_CAP * 20;
+void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset, float4 *pts, const unsigned *rank,
+                     const int *prev_idx, const int *prev_offset, const int *verified, int *idx, void *xchg, hipStream_t st);
 
 }  // namespace p2

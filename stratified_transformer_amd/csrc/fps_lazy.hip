@@ -21,8 +21,14 @@
 // ~100 rounds replace 25 000 dependent steps.  A round that accepts nothing (possible only when the candidate list
 // overflowed) falls back to ONE literal step from the bucket maxima, so progress is unconditional.
 //
-// One workgroup of 16 waves per batch element; state (pts.w = running min-dist, tie ranks, Morton order) and the
-// resume / verified-prefix conventions are fps_bucket.hip's.
+// G workgroups of 16 waves per batch element (G = 1 ... 8 by the size of the cloud).  Workgroup g OWNS a contiguous range of
+// buckets: it applies the accepted samples to them and gathers their candidates - the part of a round that scales with
+// the cloud.  The resolve step is REPLICATED: the workgroups publish their candidates in global memory, meet at ONE grid
+// barrier per round, and each of them then sorts and resolves the same list to the same accepted set (deterministic; only
+// workgroup 0 writes the indices).  The threshold of the next round is taken from a bound every workgroup knows (the
+// previous threshold / the largest bound of what was not accepted) instead of the true maximum, which would need a second
+// barrier; the true maximum arrives with the candidates and serves the literal-step fallback.
+// State (pts.w = running min-dist, tie ranks, Morton order) and the resume / verified-prefix conventions are fps_bucket.hip's.
 #include "fps_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -32,12 +38,57 @@ namespace p2 {
 constexpr int LZ_NW = 16;
 constexpr int LZ_NT = LZ_NW * 64;
 constexpr int LZ_NBL = 2;                // owned buckets per lane: up to 2 * 64 * 16 = 2048 buckets of 64 points
-constexpr int LZ_CAP = 512;              // candidates / accepted samples per round (1024 / 704: fewer rounds, each dearer: 14.3 ms against 12.3)
 constexpr int LZ_WORDS = LZ_CAP / 32;
 constexpr int LZ_TARGET = 352;           // candidates the threshold controller aims at (at most)
 constexpr int LZ_MAXSB = LZ_NBL * 64;    // super-buckets: the 16 buckets (one per wave) with the same (slot, lane)
 constexpr int LZ_GRID = 1024;            // hash cells of the candidate grid
 constexpr int LZ_HITS = 8;               // listed hitters per candidate
+
+// exchange area of one batch element (LZ_XCHG bytes, fps_common.h): barrier counter | headers [2][GMAX] | candidates [2][GMAX][CAP]
+struct LzHdr {
+    unsigned long long top;    // largest key among the workgroup's points (after its updates)
+    unsigned long long tover;  // largest key of a candidate that did not fit the workgroup's list
+    int count;                 // candidates found (may exceed LZ_CAP)
+    int pad[3];
+};
+static_assert(sizeof(LzHdr) == 32, "header layout");
+static_assert(LZ_XCHG >= 64 + 2 * LZ_GMAX * 32 + 2 * LZ_GMAX * LZ_CAP * 20, "exchange area too small");
+
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// all G workgroups of a batch element arrive; every wave of the grid reaches it the same number of times (the control flow
+// around it is replicated), so the grid always drains
+// Safety net: a workgroup that has waited LZ_PATIENCE ticks of the 100 MHz clock (2 s: the whole kernel takes milliseconds)
+// poisons the counter, which releases every waiter of the element, and all of them leave (returns false): a grid that cannot
+// make progress for a reason outside the algorithm must still drain.
+constexpr unsigned LZ_POISON = 0x40000000u;
+constexpr unsigned long long LZ_PATIENCE = 200000000ull;
+__device__ __forceinline__ bool group_barrier(unsigned *bar, unsigned target, int G, int *s_flag) {
+    __threadfence();  // release: this thread's global stores are visible device-wide before the arrival
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned v = target;
+        if (G > 1) {
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = wall_clock64();
+            while ((v = __hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > LZ_PATIENCE) {
+                    __hip_atomic_fetch_add(bar, LZ_POISON, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    v = LZ_POISON;
+                    break;
+                }
+            }
+        }
+        *s_flag = v >= LZ_POISON ? 1 : 0;
+    }
+    __syncthreads();
+    __threadfence();  // acquire side for every thread
+    return *s_flag == 0;
+}
 
 constexpr size_t lz_lds_bytes() {
     return 16 * LZ_CAP + 8 * LZ_CAP + 8 * LZ_NW + 4 * LZ_CAP * 9 + 4 * LZ_GRID + 4 * LZ_MAXSB * LZ_WORDS + 4 * 2 * LZ_MAXSB + 4 * LZ_MAXSB * 6 + 4 * 2 * LZ_WORDS +
@@ -64,8 +115,9 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
                                                          const int *__restrict__ new_offset, float4 *__restrict__ pts,
                                                          const unsigned *__restrict__ rank, const int *__restrict__ prev_idx,
                                                          const int *__restrict__ prev_offset, const int *__restrict__ verified,
-                                                         int *__restrict__ idx, unsigned long long *__restrict__ dbg = nullptr) {
-    unsigned long long c_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+                                                         int *__restrict__ idx, unsigned char *__restrict__ xchg_all,
+                                                         unsigned long long *__restrict__ dbg = nullptr) {
+    unsigned long long c_ph[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
     auto stamp = [&](int ph) {
         if (STAMP) {
             __builtin_amdgcn_s_waitcnt(0);
@@ -99,32 +151,46 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     short *gnext = reinterpret_cast<short *>(carve(2 * CAP));
     unsigned char *hcnt = carve(CAP);                                                      // number of hitters; > LZ_HITS: too many to list
     __shared__ unsigned long long s_tover, s_tdrop;
-    __shared__ int s_cnt, s_nacc, s_changed[2];
+    __shared__ int s_cnt, s_nacc, s_changed[2], s_abort;
     __shared__ unsigned s_org[3];                           // cloud origin (ord_bits of the bounding box minimum)
 
-    const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // every exit below depends on the batch element alone: the G workgroups of an element leave together
+    const int G = gridDim.x, g = blockIdx.x, bid = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
     const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
     if (end_n <= start_n) {
-        for (int j = start_m + tid; j < end_m; j += NT) idx[j] = start_n;
+        if (g == 0)
+            for (int j = start_m + tid; j < end_m; j += NT) idx[j] = start_n;
         return;
     }
     const int n = end_n - start_n, m = end_m - start_m;
     const int nb = (n + 63) / 64;
-    const int nsb = (nb + NW - 1) / NW;  // super-buckets in use (<= LZ_MAXSB)
+    const int nbw = (nb + G - 1) / G;                      // buckets per workgroup
+    const int b0 = g * nbw, nbl = max(0, min(nbw, nb - b0));  // this workgroup's buckets: [b0, b0 + nbl)
+    const int nsb = (nbl + NW - 1) / NW;                   // super-buckets in use (<= LZ_MAXSB)
+    unsigned char *xchg = xchg_all + (size_t)bid * LZ_XCHG;
+    unsigned *bar = reinterpret_cast<unsigned *>(xchg);
+    LzHdr *hdr = reinterpret_cast<LzHdr *>(xchg + 64);                                         // [2][LZ_GMAX]
+    float4 *xc4 = reinterpret_cast<float4 *>(xchg + 64 + 2 * LZ_GMAX * sizeof(LzHdr));       // [2][LZ_GMAX][CAP]
+    unsigned *xlo = reinterpret_cast<unsigned *>(xchg + 64 + 2 * LZ_GMAX * sizeof(LzHdr) + (size_t)2 * LZ_GMAX * CAP * sizeof(float4));
 
-    // samples inherited from the previous call on this state, or verified to be the identity prefix (fps_bucket.hip)
-    int done = 0;
+    // samples inherited from the previous call on this state, or verified to be the identity prefix (fps_bucket.hip);
+    // workgroup 0 writes them, everybody knows the last one
+    int done = 0, first = start_n;
     if (prev_idx) {
         const int ps = bid == 0 ? 0 : prev_offset[bid - 1], pe = prev_offset[bid];
         done = min(pe - ps, m);
-        for (int t = tid; t < done; t += NT) idx[start_m + t] = prev_idx[ps + t];
+        if (g == 0)
+            for (int t = tid; t < done; t += NT) idx[start_m + t] = prev_idx[ps + t];
+        if (done > 0) first = prev_idx[ps + done - 1];
     }
     if (verified) {
         const int v = min(verified[bid], m);
         if (v > done) {
-            for (int t = tid; t < v; t += NT) idx[start_m + t] = start_n + t;
+            if (g == 0)
+                for (int t = tid; t < v; t += NT) idx[start_m + t] = start_n + t;
             done = v;
+            first = start_n + v - 1;
         }
     }
     if (done >= m) return;
@@ -147,9 +213,9 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
 #pragma unroll
     for (int s = 0; s < NBL; s++) {
         for (int l = 0; l < 64; l++) {
-            const int bk = (s * 64 + l) * NW + wave;
-            if (bk >= nb) break;
-            const int pos = min(start_n + bk * 64 + lane, end_n - 1);
+            const int li = (s * 64 + l) * NW + wave;
+            if (li >= nbl) break;
+            const int pos = min(start_n + (b0 + li) * 64 + lane, end_n - 1);
             const float4 p = pts[pos];
             float a0 = p.x, a1 = p.y, a2 = p.z, b0 = p.x, b1 = p.y, b2 = p.z;
             for (int st = 1; st < 64; st <<= 1) {
@@ -171,14 +237,11 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             atomicMax(&sbbox[sb][3], ord_bits(mxx[s])); atomicMax(&sbbox[sb][4], ord_bits(mxy[s])); atomicMax(&sbbox[sb][5], ord_bits(mxz[s]));
             atomicMax(&sbmax[0][sb], (unsigned)(key[s] >> 32));
         }
-    if (tid < 3) s_org[tid] = 0xffffffffu;
-    if (tid == 0 && done == 0) idx[start_m] = start_n;
-    __syncthreads();  // boxes complete; the idx[] copies above are ordered before the read below
-    if (tid < 3 * LZ_MAXSB) atomicMin(&s_org[tid % 3], sbbox[tid / 3][tid % 3]);
+    if (tid == 0 && done == 0 && g == 0) idx[start_m] = start_n;
+    __syncthreads();  // boxes complete
     // the last selected sample has not been applied to the min-dist field yet (fps_bucket.hip's convention; applying a
     // sample twice is harmless): it is the first round's accepted set
     {
-        const int first = done == 0 ? start_n : idx[start_m + done - 1];
         if (tid == 0) {
             ax[0] = xyz[(size_t)first * 3 + 0];
             ay[0] = xyz[(size_t)first * 3 + 1];
@@ -188,15 +251,17 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     done = max(done, 1);
     int A = 1;                                   // accepted samples waiting to be applied
     int target = 64, lastK = 0;                  // candidates the threshold controller aims at: grows while most candidates are accepted
-    float frac = fminf(0.5f, 2.0f * 64 / (float)n);  // threshold = top min-dist * (1 - frac)
+    float frac = fminf(0.5f, 2.0f * 64 / (float)n);  // threshold = (bound of the top min-dist) * (1 - frac)
+    float bnd = INFINITY;                        // upper bound of the largest min-dist every workgroup knows (inf: nothing gathered in the first round)
     int buf = 0;                                 // sbmax[buf] = current super-bucket maxima
+    unsigned round = 0;
     __syncthreads();
 
     stamp(0);  // 0: set-up
     for (;;) {
         // ================= update: apply the A accepted samples =================
         const int nwA = (A + 31) >> 5;
-        if (STAMP) { c_ph[10] += 1; c_ph[11] += A; }
+        if (STAMP) { c_ph[12] += 1; c_ph[13] += A; }
         // (1) sample x super-bucket box tests -> sbhit; one (super-bucket, 32 samples) unit per thread trip
         for (int u = tid; u < nsb * nwA; u += NT) {
             const int sb = u / nwA, w = u - sb * nwA;
@@ -248,7 +313,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
                 for (int u = 0; u < 4; u++) {
                     ol[u] = touched ? __ffsll(touched) - 1 : -1;  // wave-uniform
                     touched &= touched - 1;                       // (0 & anything stays 0)
-                    pos[u] = min(start_n + ((s * 64 + max(ol[u], 0)) * NW + wave) * 64 + lane, end_n - 1);  // lanes past the end copy the last point
+                    pos[u] = min(start_n + (b0 + (s * 64 + max(ol[u], 0)) * NW + wave) * 64 + lane, end_n - 1);  // lanes past the end copy the last point
                     if (ol[u] >= 0) { p[u] = pts[pos[u]]; rk[u] = rank[pos[u]]; }
                 }
 #pragma unroll
@@ -295,20 +360,23 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
         }
         buf ^= 1;
         if (tid == 0) { s_cnt = 0; s_tover = 0ull; s_tdrop = 0ull; s_nacc = 0; s_changed[0] = 0; s_changed[1] = 0; }
+        if (tid < 3) s_org[tid] = 0xffffffffu;
         for (int t = tid; t < LZ_GRID; t += NT) ghead[t] = -1;
         __syncthreads();
         stamp(4);  // 4: maxima + barrier (waiting for the slowest wave's updates)
-        if (done >= m) break;  // (uniform) everything selected, and applied
-        unsigned long long gtop = 0ull;
+        if (done >= m) break;  // (uniform, and the same in every workgroup) everything selected, and applied
+        unsigned long long ltop = 0ull;  // this workgroup's largest key
         {
             const unsigned long long v = lane < NW ? wkey[lane] : 0ull;
-            gtop = wave_key_max(v).key;
+            ltop = wave_key_max(v).key;
         }
-        const float dtop = __uint_as_float((unsigned)(gtop >> 32));
-        // ---- gather the candidates: every point with min-dist >= tau (two tighter retries if the list overflows) ----
-        int K = 0;
-        for (int attempt = 0;; attempt++) {
-            const unsigned taub = __float_as_uint(fmaxf(dtop * (1.0f - frac), 0.f));
+        // ---- gather this workgroup's candidates: every point with min-dist >= tau -> its list in the exchange area ----
+        const int par = round & 1;
+        const float tau = fmaxf(bnd * (1.0f - frac), 0.f);
+        const unsigned taub = __float_as_uint(tau);
+        {
+            float4 *my4 = xc4 + ((size_t)par * LZ_GMAX + g) * CAP;
+            unsigned *mylo = xlo + ((size_t)par * LZ_GMAX + g) * CAP;
 #pragma unroll
             for (int s = 0; s < NBL; s++) {
                 unsigned long long have = __ballot(mnx[s] != INFINITY && (unsigned)(key[s] >> 32) >= taub);
@@ -320,7 +388,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
                     for (int u = 0; u < 4; u++) {
                         ol[u] = have ? __ffsll(have) - 1 : -1;
                         have &= have - 1;
-                        pos[u] = start_n + ((s * 64 + max(ol[u], 0)) * NW + wave) * 64 + lane;
+                        pos[u] = start_n + (b0 + (s * 64 + max(ol[u], 0)) * NW + wave) * 64 + lane;
                         if (ol[u] >= 0) { p[u] = pts[min(pos[u], end_n - 1)]; rk[u] = rank[min(pos[u], end_n - 1)]; }
                     }
 #pragma unroll
@@ -335,7 +403,8 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
                             if (cand) {
                                 const int at = base + __popcll(cm & ((1ull << lane) - 1ull));
                                 if (at < CAP) {
-                                    cx[at] = p[u].x; cy[at] = p[u].y; cz[at] = p[u].z; cd[at] = p[u].w; clo[at] = rk[u];
+                                    my4[at] = p[u];
+                                    mylo[at] = rk[u];
                                 } else {
                                     atomicMax(&s_tover, ((unsigned long long)__float_as_uint(p[u].w) << 32) | rk[u]);
                                 }
@@ -344,23 +413,61 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
                     }
                 }
             }
-            __syncthreads();
-            const int found = s_cnt;
-            K = min(found, CAP);
-            // threshold controller (every thread computes the same): aim at LZ_TARGET candidates
-            const float ratio = fminf(fmaxf((float)target / (float)max(found, 1), 0.5f), 2.0f);
-            if (found > CAP && attempt < 2 && frac > 1e-7f) {
-                frac *= 0.25f * (float)CAP / (float)found;
-                __syncthreads();  // everybody has read s_cnt
-                if (tid == 0) { s_cnt = 0; s_tover = 0ull; }
-                __syncthreads();
-                continue;
-            }
-            frac = fminf(fmaxf(frac * ratio, 1e-7f), 0.5f);
-            break;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            LzHdr *h = hdr + par * LZ_GMAX + g;
+            st_agent(&h->top, ltop);
+            st_agent(&h->tover, (unsigned long long)s_tover);
+            st_agent(&h->count, (int)s_cnt);
         }
         stamp(5);  // 5: gather
-        const unsigned long long tover = s_tover;
+        round++;
+        if (!group_barrier(bar, round * (unsigned)G, G, &s_abort)) return;  // (uniform in the workgroup; see LZ_PATIENCE)
+        stamp(10);  // 10: waiting for the other workgroups
+        // ---- everybody reads everybody's list (in workgroup order, cut at CAP: what is cut is bounded by its workgroup's top) ----
+        int K = 0, found = 0;
+        unsigned long long gtop = 0ull, tover = 0ull;
+        int gbase[LZ_GMAX + 1];
+#pragma unroll
+        for (int gg = 0; gg < LZ_GMAX; gg++) {
+            gbase[gg] = K;
+            if (gg < G) {
+                const LzHdr *h = hdr + par * LZ_GMAX + gg;
+                const unsigned long long tp = ld_agent(&h->top), tv = ld_agent(&h->tover);
+                const int c = ld_agent(&h->count);
+                found += c;
+                gtop = tp > gtop ? tp : gtop;
+                tover = tv > tover ? tv : tover;
+                const int keep = min(c, CAP), take = min(keep, CAP - K);
+                if (take < keep) tover = tp > tover ? tp : tover;
+                K += take;
+            }
+        }
+        gbase[LZ_GMAX] = K;
+        for (int t = tid; t < K; t += NT) {
+            int gg = 0;
+#pragma unroll
+            for (int q = 1; q < LZ_GMAX; q++) gg += (q < G && t >= gbase[q]) ? 1 : 0;
+            int gb = 0;
+#pragma unroll
+            for (int q = 0; q < LZ_GMAX; q++) gb = q == gg ? gbase[q] : gb;
+            const size_t at = ((size_t)par * LZ_GMAX + gg) * CAP + (t - gb);
+            const float *src = reinterpret_cast<const float *>(xc4 + at);
+            const float x = ld_agent(src + 0), y = ld_agent(src + 1), z = ld_agent(src + 2), d = ld_agent(src + 3);
+            cx[t] = x; cy[t] = y; cz[t] = z; cd[t] = d;
+            clo[t] = ld_agent(xlo + at);
+            atomicMin(&s_org[0], ord_bits(x)); atomicMin(&s_org[1], ord_bits(y)); atomicMin(&s_org[2], ord_bits(z));
+        }
+        const float dtop = __uint_as_float((unsigned)(gtop >> 32));
+        {
+            // threshold controller (every thread of every workgroup computes the same): aim at `target` candidates
+            const float ratio = fminf(fmaxf((float)target / (float)max(found, 1), 0.5f), 2.0f);
+            if (found > CAP) frac = fmaxf(frac * 0.25f * (float)CAP / (float)found, 1e-7f);
+            else frac = fminf(fmaxf(frac * ratio, 1e-7f), 0.5f);
+        }
+        __syncthreads();
+        stamp(11);  // 11: reading the lists
         lastK = K;
         // ---- sort the candidates by key, descending: sorted position = the order the reference would select them in ----
         int P2 = 2;
@@ -478,8 +585,8 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             }
         }
         __syncthreads();
+        const unsigned long long tcut = tover > s_tdrop ? tover : s_tdrop;
         {
-            const unsigned long long tcut = tover > s_tdrop ? tover : s_tdrop;
             const int remaining = m - done;
             const bool fin0 = acc && kj > tcut;  // keys descend with the position: the accepted set is a prefix of the acc set
             const unsigned long long fm0 = __ballot(fin0);
@@ -496,7 +603,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             const bool fin = fin0 && r < remaining;
             if (fin) {
                 ax[r] = px; ay[r] = py; az[r] = pz;
-                idx[start_m + done + r] = start_n + rel_of(kj, Bref, log2B);
+                if (g == 0) idx[start_m + done + r] = start_n + rel_of(kj, Bref, log2B);
             }
             const unsigned long long fm = __ballot(fin);
             if (lane == 0 && fm) atomicAdd(&s_nacc, __popcll(fm));
@@ -506,43 +613,61 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
         // few candidates while they get in each other's way (the early rounds), many once most of them are accepted
         if (A * 2 > lastK) target = min(target + target / 2, LZ_TARGET);
         else if (A * 4 < lastK) target = max(target / 2, 32);
+        // what is left is bounded: points that were no candidates lie below tau, candidates that were not accepted at or below
+        // the cut, and nothing exceeds the maximum the lists came with
+        bnd = fminf(dtop, fmaxf(tau, __uint_as_float((unsigned)(tcut >> 32))));
         if (A == 0) {
-            // nothing could be decided (the candidate list overflowed above the best candidate): one literal step
+            // nothing could be decided (no candidate reached the threshold - the first round, or a bound far above the true
+            // maximum - or the list overflowed above the best candidate): one literal step from the true maximum
             if (tid == 0) {
                 const int w = start_n + rel_of(gtop, Bref, log2B);
                 ax[0] = xyz[(size_t)w * 3 + 0]; ay[0] = xyz[(size_t)w * 3 + 1]; az[0] = xyz[(size_t)w * 3 + 2];
-                idx[start_m + done] = w;
+                if (g == 0) idx[start_m + done] = w;
             }
             A = 1;
+            bnd = dtop;
             __syncthreads();
         }
         done += A;
         stamp(9);  // 9: bounds, ranks, output
     }
-    if (STAMP && dbg && tid == 0)
-        for (int i = 0; i < 12; i++) dbg[blockIdx.x * 12 + i] = c_ph[i];
+    if (STAMP && dbg && tid == 0 && g == 0)
+        for (int i = 0; i < 14; i++) dbg[bid * 14 + i] = c_ph[i];
 }
 
-void fps_lazy_launch(int b, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset, float4 *pts, const unsigned *rank,
-                     const int *prev_idx, const int *prev_offset, const int *verified, int *idx, hipStream_t st) {
+// workgroups per batch element: a workgroup should own ~100+ buckets for its share of a round to outweigh the barrier;
+// all b * G workgroups must be resident together (they wait for each other), so large batches get fewer
+static int lz_groups(int b, int n_max) {
+    static const int env = getenv("P2_FPS_GROUPS") ? atoi(getenv("P2_FPS_GROUPS")) : 0;
+    const int nb = (n_max + 63) / 64;
+    int G = env > 0 ? env : nb / 96;
+    G = std::max(1, std::min(G, LZ_GMAX));
+    while (G > 1 && b * G > 64) G--;
+    return G;
+}
+
+void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset, float4 *pts, const unsigned *rank,
+                     const int *prev_idx, const int *prev_offset, const int *verified, int *idx, void *xchg, hipStream_t st) {
     allow_big_lds(fps_lazy_kernel<false>, lz_lds_bytes());
     allow_big_lds(fps_lazy_kernel<true>, lz_lds_bytes());
-    if (getenv("P2_FPS_STAMPS")) {  // diagnostic only: synchronous, prints the phase cycles of wave 0 to stderr
-        unsigned long long *dbg = nullptr, host[12];
+    const int G = lz_groups(b, n_max);
+    (void)hipMemsetAsync(xchg, 0, (size_t)b * LZ_XCHG, st);  // barrier counters (and headers)
+    if (getenv("P2_FPS_STAMPS")) {  // diagnostic only: synchronous, prints the phase cycles of wave 0 of workgroup 0 to stderr
+        unsigned long long *dbg = nullptr, host[14];
         (void)hipMalloc(&dbg, sizeof(host) * b);
         (void)hipMemset(dbg, 0, sizeof(host) * b);
-        hipLaunchKernelGGL(fps_lazy_kernel<true>, dim3(b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
-                           verified, idx, dbg);
+        hipLaunchKernelGGL(fps_lazy_kernel<true>, dim3(G, b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
+                           verified, idx, (unsigned char *)xchg, dbg);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
         (void)hipFree(dbg);
-        fprintf(stderr, "[fps lazy] rounds %llu samples %llu | cycles: setup %llu sbtests %llu owntests %llu updates %llu maxima+wait %llu gather %llu sort %llu "
-                        "hitters %llu fixedpoint %llu output %llu\n", host[10], host[11], host[0], host[1], host[2], host[3], host[4], host[5], host[6], host[7], host[8],
-                host[9]);
+        fprintf(stderr, "[fps lazy] G %d rounds %llu samples %llu | cycles: setup %llu sbtests %llu owntests %llu updates %llu maxima+wait %llu gather %llu gridwait %llu "
+                        "lists %llu sort %llu hitters %llu fixedpoint %llu output %llu\n", G, host[12], host[13], host[0], host[1], host[2], host[3], host[4], host[5],
+                host[10], host[11], host[6], host[7], host[8], host[9]);
         return;
     }
-    hipLaunchKernelGGL(fps_lazy_kernel<false>, dim3(b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
-                       verified, idx, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(fps_lazy_kernel<false>, dim3(G, b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
+                       verified, idx, (unsigned char *)xchg, (unsigned long long *)nullptr);
 }
 
 }  // namespace p2

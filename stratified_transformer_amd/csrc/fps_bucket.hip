@@ -657,11 +657,24 @@ static int bits_for(int b) {
     while ((1 << r) < b) r++;
     return r;
 }
+constexpr int FPS_HEAD_MAX = 4096;  // samples of a cloud the round sampler may leave to the step-by-step kernel (P2_FPS_HEAD)
+
 static size_t fps_cub_bytes(int b, int N) {
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                              (const int *)nullptr, (int *)nullptr, N, 0, 32 + bits_for(b), (hipStream_t) nullptr);
     return bytes;
+}
+
+// request of the sampling chain's head (fps_bucket_launch): the first `head` samples of every cloud
+__global__ void fps_head_offsets_kernel(int b, int head, const int *__restrict__ new_offset, int *__restrict__ head_offset) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int acc = 0;
+    for (int i = 0; i < b; i++) {
+        const int m = new_offset[i] - (i ? new_offset[i - 1] : 0);
+        acc += min(m, head);
+        head_offset[i] = acc;
+    }
 }
 
 struct FpsResume {
@@ -696,6 +709,8 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     unsigned long long *thr = (unsigned long long *)p; p += f8;    // verification thresholds
     int *first_bad = (int *)p; p += al((size_t)b * 4);
     void *xchg = p; p += al((size_t)b * LZ_XCHG);                  // where the round sampler's workgroups meet (fps_lazy.hip)
+    int *head_offset = (int *)p; p += al((size_t)b * 4);            // the chain's head, sampled step by step (below)
+    int *head_idx = (int *)p; p += al((size_t)b * FPS_HEAD_MAX * 4);
     void *cub_tmp = p;
     size_t cub_bytes = w.bytes - (size_t)(p - reinterpret_cast<char *>(w.ptr));
     FpsResume rs = fps_resume();
@@ -723,30 +738,53 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     }
     const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);
     const int nbuckets = div_up(n, BSZ);
-    // round-based sampler (fps_lazy.hip) on the same state; P2_FPS_STEPWISE=1 keeps the step-by-step kernel below
-    static const bool stepwise = getenv("P2_FPS_STEPWISE") != nullptr;
-    if (BSZ == 64 && !stepwise) {
-        fps_lazy_launch(b, n, Bref, log2B, xyz, offset, new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, xchg, st);
-        return true;
-    }
     static const int nw_env = getenv("P2_FPS_WAVES") ? atoi(getenv("P2_FPS_WAVES")) : 0;
     const int NWsel = nw_env == 8 ? 8 : 16;
     const int per_lane = div_up(nbuckets, NWsel * 64);
-#define P2_FPS_LAUNCH(NBL_, NW_, STAMP_, DBG_)                                                                              \
+#define P2_FPS_LAUNCH(NBL_, NW_, STAMP_, DBG_, NEWOFF_, PIDX_, POFF_, IDX_)                                                 \
     do {                                                                                                                    \
         if (BSZ == 64)                                                                                                      \
             hipLaunchKernelGGL((fps_bucket_kernel<NBL_, NW_, STAMP_, true>), dim3(b), dim3(NW_ * 64), 0, st, Bref, log2B, BSZ, xyz, \
-                               offset, new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, DBG_);            \
+                               offset, NEWOFF_, pts, rank, PIDX_, POFF_, verified, IDX_, DBG_);                             \
         else                                                                                                                \
             hipLaunchKernelGGL((fps_bucket_kernel<NBL_, NW_, STAMP_, false>), dim3(b), dim3(NW_ * 64), 0, st, Bref, log2B, BSZ, xyz, \
-                               offset, new_offset, pts, rank, rs.prev_idx, rs.prev_offset, verified, idx, DBG_);            \
+                               offset, NEWOFF_, pts, rank, PIDX_, POFF_, verified, IDX_, DBG_);                             \
     } while (0)
+#define P2_FPS_STEPWISE(NEWOFF_, PIDX_, POFF_, IDX_)                                                                       \
+    do {                                                                                                                    \
+        if (NWsel == 8) {                                                                                                   \
+            if (per_lane <= 1) P2_FPS_LAUNCH(1, 8, false, nullptr, NEWOFF_, PIDX_, POFF_, IDX_);                            \
+            else if (per_lane <= 2) P2_FPS_LAUNCH(2, 8, false, nullptr, NEWOFF_, PIDX_, POFF_, IDX_);                       \
+            else P2_FPS_LAUNCH(4, 8, false, nullptr, NEWOFF_, PIDX_, POFF_, IDX_);                                          \
+        } else {                                                                                                            \
+            if (per_lane <= 1) P2_FPS_LAUNCH(1, 16, false, nullptr, NEWOFF_, PIDX_, POFF_, IDX_);                           \
+            else P2_FPS_LAUNCH(2, 16, false, nullptr, NEWOFF_, PIDX_, POFF_, IDX_);                                         \
+        }                                                                                                                   \
+    } while (0)
+    // Round-based sampler (fps_lazy.hip) on the same state; P2_FPS_STEPWISE=1 keeps the step-by-step kernel.  The first few
+    // hundred samples of a fresh chain interact so strongly that a round decides one or two of them (and a round costs what
+    // ~30 dependent steps cost): the HEAD of the chain is therefore sampled step by step and the rounds resume from it -
+    // same state conventions, same sequence.
+    static const bool stepwise = getenv("P2_FPS_STEPWISE") != nullptr;
+    if (!stepwise && fps_lazy_groups(n) > 0) {
+        static const int head_env = getenv("P2_FPS_HEAD") ? atoi(getenv("P2_FPS_HEAD")) : 256;
+        const int head = std::min(std::max(head_env, 0), FPS_HEAD_MAX);
+        const int *pidx = rs.prev_idx, *poff = rs.prev_offset;
+        if (pidx == nullptr && head > 0 && n >= 8192) {
+            hipLaunchKernelGGL(fps_head_offsets_kernel, dim3(1), dim3(64), 0, st, b, head, new_offset, head_offset);
+            P2_FPS_STEPWISE(head_offset, (const int *)nullptr, (const int *)nullptr, head_idx);
+            pidx = head_idx;
+            poff = head_offset;
+        }
+        fps_lazy_launch(b, n, Bref, log2B, xyz, offset, new_offset, pts, rank, pidx, poff, verified, idx, xchg, st);
+        return true;
+    }
     if (getenv("P2_FPS_STAMPS") && nbuckets > 1024) {  // diagnostic only: synchronous, prints phase shares to stderr
         unsigned long long *dbg = nullptr, host[16 * 8];
         const size_t trace_words = (size_t)FPS_TRACE_STEPS * 16 * 8;
         (void)hipMalloc(&dbg, (sizeof(host) + trace_words * 8) * b);
         (void)hipMemset(dbg, 0, (sizeof(host) + trace_words * 8) * b);
-        if (NWsel == 8) P2_FPS_LAUNCH(4, 8, true, dbg); else P2_FPS_LAUNCH(2, 16, true, dbg);
+        if (NWsel == 8) P2_FPS_LAUNCH(4, 8, true, dbg, new_offset, rs.prev_idx, rs.prev_offset, idx); else P2_FPS_LAUNCH(2, 16, true, dbg, new_offset, rs.prev_idx, rs.prev_offset, idx);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
         if (const char *tf = getenv("P2_FPS_TRACE")) {
@@ -762,14 +800,8 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
                     host[w * 8 + 7] ? 100.0 * host[w * 8 + 6] / host[w * 8 + 7] : 0.0);
         return true;
     }
-    if (NWsel == 8) {
-        if (per_lane <= 1) P2_FPS_LAUNCH(1, 8, false, nullptr);
-        else if (per_lane <= 2) P2_FPS_LAUNCH(2, 8, false, nullptr);
-        else P2_FPS_LAUNCH(4, 8, false, nullptr);
-    } else {
-        if (per_lane <= 1) P2_FPS_LAUNCH(1, 16, false, nullptr);
-        else P2_FPS_LAUNCH(2, 16, false, nullptr);
-    }
+    P2_FPS_STEPWISE(new_offset, rs.prev_idx, rs.prev_offset, idx);
+#undef P2_FPS_STEPWISE
 #undef P2_FPS_LAUNCH
     return true;
 }
@@ -787,7 +819,8 @@ void pointops2_set_workspace(void *ptr, size_t bytes) {
 
 size_t pointops2_fps_workspace_bytes(int b, int N) {
     if (b <= 0 || N <= 0) return 0;
-    return al((size_t)N * 16) + 4 * al((size_t)N * 4) + 3 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al((size_t)b * 4) + al((size_t)b * LZ_XCHG) + al(fps_cub_bytes(b, N));
+    return al((size_t)N * 16) + 4 * al((size_t)N * 4) + 3 * al((size_t)N * 8) + al((size_t)b * 6 * 4) + al((size_t)b * 4) + al((size_t)b * LZ_XCHG) + al((size_t)b * 4) + al((size_t)b * FPS_HEAD_MAX * 4) +
+           al(fps_cub_bytes(b, N));
 }
 
 void pointops2_set_fps_resume(const int *prev_idx, const int *prev_offset) {

@@ -50,7 +50,9 @@ __device__ __forceinline__ float rl(float v, int lane) {  // value of a wave-uni
 // fps_lazy.hip: the round-based sampler on the state fps_bucket_launch prepares; same arguments as fps_bucket_kernel plus the
 // exchange area its workgroups meet in (b * LZ_XCHG bytes of the workspace) and the largest cloud of the batch
 constexpr int LZ_CAP = 512;    // candidates / accepted samples per round (1024 / 704: fewer rounds, each dearer: 14.3 ms against 12.3)
-constexpr int LZ_GMAX = 8;     // workgroups per batch element, at most
+constexpr int LZ_GMAX = 16;    // workgroups per batch element, at most
+constexpr int LZ_NSLOT = 14;   // buckets of 64 points a wave keeps in registers (16 waves per workgroup)
+int fps_lazy_groups(int n_max);  // workgroups the round sampler would use for a cloud of n_max points; 0: too large for it
 constexpr size_t LZ_XCHG = 64 + 2 * LZ_GMAX * 32 + 2 * LZ_GMAX * LZ_CAP * 20;
 void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset, float4 *pts, const unsigned *rank,
                      const int *prev_idx, const int *prev_offset, const int *verified, int *idx, void *xchg, hipStream_t st);

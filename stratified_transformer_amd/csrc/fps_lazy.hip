@@ -15,21 +15,25 @@
 //               distance to the accepted candidates that hit it; nothing below the largest such bound (or below a
 //               candidate that did not fit the list) is accepted in this round - it waits for the next one;
 //   update      the accepted samples are applied to the cloud together: min-dist = min over the new samples, bucket by
-//               bucket as in fps_bucket.hip (points Morton-sorted in buckets of 64 with boxes; a bucket is skipped when
-//               no accepted sample can reach it), with a two-level box test (16-bucket super-buckets first).
+//               bucket (points Morton-sorted in buckets of 64 with boxes; a bucket is skipped when no accepted sample
+//               can reach it), with a two-level box test (16-bucket super-buckets first).
 // The index sequence is the reference's, bit for bit (same fma chain, same tie ranks, min() is order-independent);
-// ~100 rounds replace 25 000 dependent steps.  A round that accepts nothing (possible only when the candidate list
-// overflowed) falls back to ONE literal step from the bucket maxima, so progress is unconditional.
+// ~170 rounds replace 25 000 dependent steps.  A round that accepts nothing (no candidate reached the threshold, or the
+// candidate list overflowed above the best candidate) falls back to ONE literal step from the true maximum, so progress is
+// unconditional.
 //
-// G workgroups of 16 waves per batch element (G = 1 ... 8 by the size of the cloud).  Workgroup g OWNS a contiguous range of
-// buckets: it applies the accepted samples to them and gathers their candidates - the part of a round that scales with
-// the cloud.  The resolve step is REPLICATED: the workgroups publish their candidates in global memory, meet at ONE grid
-// barrier per round, and each of them then sorts and resolves the same list to the same accepted set (deterministic; only
-// workgroup 0 writes the indices).  The threshold of the next round is taken from a bound every workgroup knows (the
-// previous threshold / the largest bound of what was not accepted) instead of the true maximum, which would need a second
-// barrier; the true maximum arrives with the candidates and serves the literal-step fallback.
-// State (pts.w = running min-dist, tie ranks, Morton order) and the resume / verified-prefix conventions are fps_bucket.hip's.
+// G workgroups of 16 waves per batch element (G = 1 ... 16 by the size of the cloud).  Workgroup g OWNS a contiguous range
+// of buckets and keeps their points IN REGISTERS for the whole kernel (lane <-> point of a bucket, up to LZ_NSLOT buckets per
+// wave): applying samples and gathering candidates - the part of a round that scales with the cloud - touches no memory.
+// The resolve step is REPLICATED: the workgroups publish their candidates in global memory, meet at ONE grid barrier per
+// round, and each of them then sorts and resolves the same list to the same accepted set (deterministic; only workgroup 0
+// writes the indices).  The threshold of the next round is taken from a bound every workgroup knows (the previous threshold /
+// the largest bound of what was not accepted) instead of the true maximum, which would need a second barrier; the true
+// maximum arrives with the candidates and serves the literal-step fallback.
+// State (pts.w = running min-dist, written back at the end; tie ranks; Morton order) and the resume / verified-prefix
+// conventions are fps_bucket.hip's.
 #include "fps_common.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -37,12 +41,11 @@ namespace p2 {
 
 constexpr int LZ_NW = 16;
 constexpr int LZ_NT = LZ_NW * 64;
-constexpr int LZ_NBL = 2;                // owned buckets per lane: up to 2 * 64 * 16 = 2048 buckets of 64 points
 constexpr int LZ_WORDS = LZ_CAP / 32;
 constexpr int LZ_TARGET = 352;           // candidates the threshold controller aims at (at most)
-constexpr int LZ_MAXSB = LZ_NBL * 64;    // super-buckets: the 16 buckets (one per wave) with the same (slot, lane)
 constexpr int LZ_GRID = 1024;            // hash cells of the candidate grid
 constexpr int LZ_HITS = 8;               // listed hitters per candidate
+constexpr int LZ_PAIRS_MAX = 128;        // up to this many candidates the hitters are found by testing all pairs
 
 // exchange area of one batch element (LZ_XCHG bytes, fps_common.h): barrier counter | headers [2][GMAX] | candidates [2][GMAX][CAP]
 struct LzHdr {
@@ -53,22 +56,23 @@ struct LzHdr {
 };
 static_assert(sizeof(LzHdr) == 32, "header layout");
 static_assert(LZ_XCHG >= 64 + 2 * LZ_GMAX * 32 + 2 * LZ_GMAX * LZ_CAP * 20, "exchange area too small");
+static_assert(LZ_NT / LZ_GMAX >= 64, "a wave reads entries of one workgroup's list");
 
 template <typename T>
 __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T>
 __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// all G workgroups of a batch element arrive; every wave of the grid reaches it the same number of times (the control flow
-// around it is replicated), so the grid always drains
+// All G workgroups of a batch element arrive; every workgroup reaches it the same number of times (the control flow around
+// it is replicated), so the grid always drains.  Cross-workgroup data is written and read with device-scope accesses; the
+// workgroup barriers order the other threads' accesses around thread 0's release / acquire.
 // Safety net: a workgroup that has waited LZ_PATIENCE ticks of the 100 MHz clock (2 s: the whole kernel takes milliseconds)
 // poisons the counter, which releases every waiter of the element, and all of them leave (returns false): a grid that cannot
 // make progress for a reason outside the algorithm must still drain.
 constexpr unsigned LZ_POISON = 0x40000000u;
 constexpr unsigned long long LZ_PATIENCE = 200000000ull;
 __device__ __forceinline__ bool group_barrier(unsigned *bar, unsigned target, int G, int *s_flag) {
-    __threadfence();  // release: this thread's global stores are visible device-wide before the arrival
-    __syncthreads();
+    __syncthreads();  // (workgroup-scope release: every wave's stores have left the CU)
     if (threadIdx.x == 0) {
         unsigned v = target;
         if (G > 1) {
@@ -86,13 +90,12 @@ __device__ __forceinline__ bool group_barrier(unsigned *bar, unsigned target, in
         *s_flag = v >= LZ_POISON ? 1 : 0;
     }
     __syncthreads();
-    __threadfence();  // acquire side for every thread
     return *s_flag == 0;
 }
 
 constexpr size_t lz_lds_bytes() {
-    return 16 * LZ_CAP + 8 * LZ_CAP + 8 * LZ_NW + 4 * LZ_CAP * 9 + 4 * LZ_GRID + 4 * LZ_MAXSB * LZ_WORDS + 4 * 2 * LZ_MAXSB + 4 * LZ_MAXSB * 6 + 4 * 2 * LZ_WORDS +
-           2 * LZ_CAP * LZ_HITS + 2 * LZ_CAP * 2 + LZ_CAP + 16 * 24;  // (+ alignment slack)
+    return 16 * LZ_CAP + 8 * LZ_CAP + 8 * LZ_NW + 4 * LZ_CAP * 9 + 4 * LZ_GRID + 4 * LZ_NSLOT * LZ_WORDS + 4 * 2 * LZ_NSLOT + 4 * LZ_NSLOT * 6 + 4 * 2 * LZ_WORDS +
+           2 * LZ_CAP * LZ_HITS + 2 * LZ_CAP * 2 + 4 * LZ_CAP + 16 * 24;  // (+ alignment slack)
 }
 
 __device__ __forceinline__ unsigned ord_bits(float v) {  // order-preserving float -> unsigned
@@ -108,10 +111,16 @@ __device__ __forceinline__ float box_lb(float x, float y, float z, float mnx, fl
     const float dz = fmaxf(fmaxf(mnz - z, z - mxz), 0.f);
     return sqd(dx, dy, dz);
 }
+__device__ __forceinline__ unsigned cell_hash(int x, int y, int z) {
+    return ((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (LZ_GRID - 1);
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+}
 
-// STAMP: diagnostic build only (P2_FPS_STAMPS=1): cycle sums of the phases of wave 0 and round statistics -> dbg
-template <bool STAMP>
-__global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, const float *__restrict__ xyz, const int *__restrict__ offset,
+// STAMP: diagnostic build only (P2_FPS_STAMPS=1): cycle sums of the phases of wave 0 of workgroup 0 and round statistics -> dbg
+template <bool STAMP, int NSLOT>
+__global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, int bid0, const float *__restrict__ xyz, const int *__restrict__ offset,
                                                          const int *__restrict__ new_offset, float4 *__restrict__ pts,
                                                          const unsigned *__restrict__ rank, const int *__restrict__ prev_idx,
                                                          const int *__restrict__ prev_offset, const int *__restrict__ verified,
@@ -127,7 +136,8 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
         }
     };
     if (STAMP) t_last = __builtin_amdgcn_s_memtime();
-    constexpr int NW = LZ_NW, NT = LZ_NT, NBL = LZ_NBL, CAP = LZ_CAP, WORDS = LZ_WORDS;
+    constexpr int NW = LZ_NW, NT = LZ_NT, CAP = LZ_CAP, WORDS = LZ_WORDS;
+    static_assert(NSLOT <= LZ_NSLOT, "LDS is sized for LZ_NSLOT super-buckets");
     // LDS: carved from one dynamic block (more than the 64 KiB a kernel may declare statically)
     extern __shared__ unsigned char lz_lds[];
     unsigned char *lp = lz_lds;
@@ -135,27 +145,26 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     float4 *sp4 = reinterpret_cast<float4 *>(carve(sizeof(float4) * CAP));                 // candidate (x, y, z, min-dist), by sorted position
     unsigned long long *skey = reinterpret_cast<unsigned long long *>(carve(8 * CAP));     // candidate keys, sorted descending (the reference's selection order)
     unsigned long long *wkey = reinterpret_cast<unsigned long long *>(carve(8 * NW));
-    float *cx = reinterpret_cast<float *>(carve(4 * CAP)), *cy = reinterpret_cast<float *>(carve(4 * CAP));  // candidates, in gather order
+    float *cx = reinterpret_cast<float *>(carve(4 * CAP)), *cy = reinterpret_cast<float *>(carve(4 * CAP));  // candidates, in list order
     float *cz = reinterpret_cast<float *>(carve(4 * CAP)), *cd = reinterpret_cast<float *>(carve(4 * CAP));
     unsigned *clo = reinterpret_cast<unsigned *>(carve(4 * CAP));
     unsigned *ccell = reinterpret_cast<unsigned *>(carve(4 * CAP));                        // candidate's grid cell (10 bits per axis), by sorted position
     int *ghead = reinterpret_cast<int *>(carve(4 * LZ_GRID));                              // hash grid over the candidates: chains of sorted positions
     float *ax = reinterpret_cast<float *>(carve(4 * CAP)), *ay = reinterpret_cast<float *>(carve(4 * CAP));  // accepted samples, in selection order
     float *az = reinterpret_cast<float *>(carve(4 * CAP));
-    unsigned (*sbhit)[WORDS] = reinterpret_cast<unsigned (*)[WORDS]>(carve(4 * LZ_MAXSB * WORDS));  // accepted samples that may reach a super-bucket
-    unsigned (*sbmax)[LZ_MAXSB] = reinterpret_cast<unsigned (*)[LZ_MAXSB]>(carve(4 * 2 * LZ_MAXSB));  // largest min-dist (bits) inside a super-bucket, double-buffered
-    unsigned (*sbbox)[6] = reinterpret_cast<unsigned (*)[6]>(carve(4 * LZ_MAXSB * 6));     // super-bucket boxes (ord_bits)
+    unsigned (*sbhit)[WORDS] = reinterpret_cast<unsigned (*)[WORDS]>(carve(4 * LZ_NSLOT * WORDS));  // accepted samples that may reach a super-bucket
+    unsigned (*sbmax)[LZ_NSLOT] = reinterpret_cast<unsigned (*)[LZ_NSLOT]>(carve(4 * 2 * LZ_NSLOT));      // largest min-dist (bits) inside a super-bucket, double-buffered
+    unsigned (*sbbox)[6] = reinterpret_cast<unsigned (*)[6]>(carve(4 * LZ_NSLOT * 6));              // super-bucket boxes (ord_bits)
     unsigned (*accw)[WORDS] = reinterpret_cast<unsigned (*)[WORDS]>(carve(4 * 2 * WORDS));
     unsigned short (*hl)[LZ_HITS] = reinterpret_cast<unsigned short (*)[LZ_HITS]>(carve(2 * CAP * LZ_HITS));  // hitters of a candidate (sorted positions, all with larger keys)
-    unsigned short *sidx = reinterpret_cast<unsigned short *>(carve(2 * CAP));             // sorted position -> candidate slot
+    unsigned short *sidx = reinterpret_cast<unsigned short *>(carve(2 * CAP));             // sorted position -> list slot
     short *gnext = reinterpret_cast<short *>(carve(2 * CAP));
-    unsigned char *hcnt = carve(CAP);                                                      // number of hitters; > LZ_HITS: too many to list
+    int *hcnt = reinterpret_cast<int *>(carve(4 * CAP));                                   // number of hitters; > LZ_HITS: too many to list
     __shared__ unsigned long long s_tover, s_tdrop;
     __shared__ int s_cnt, s_nacc, s_changed[2], s_abort;
-    __shared__ unsigned s_org[3];                           // cloud origin (ord_bits of the bounding box minimum)
 
     // every exit below depends on the batch element alone: the G workgroups of an element leave together
-    const int G = gridDim.x, g = blockIdx.x, bid = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x, g = blockIdx.x, bid = bid0 + blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start_n = bid == 0 ? 0 : offset[bid - 1], end_n = offset[bid];
     const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
     if (end_n <= start_n) {
@@ -165,13 +174,13 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     }
     const int n = end_n - start_n, m = end_m - start_m;
     const int nb = (n + 63) / 64;
-    const int nbw = (nb + G - 1) / G;                      // buckets per workgroup
+    const int nbw = (nb + G - 1) / G;                         // buckets per workgroup (<= NW * NSLOT: the launcher's choice of G)
     const int b0 = g * nbw, nbl = max(0, min(nbw, nb - b0));  // this workgroup's buckets: [b0, b0 + nbl)
-    const int nsb = (nbl + NW - 1) / NW;                   // super-buckets in use (<= LZ_MAXSB)
+    const int nsb = (nbl + NW - 1) / NW;                      // super-buckets in use (<= NSLOT): the buckets of one register slot
     unsigned char *xchg = xchg_all + (size_t)bid * LZ_XCHG;
     unsigned *bar = reinterpret_cast<unsigned *>(xchg);
     LzHdr *hdr = reinterpret_cast<LzHdr *>(xchg + 64);                                         // [2][LZ_GMAX]
-    float4 *xc4 = reinterpret_cast<float4 *>(xchg + 64 + 2 * LZ_GMAX * sizeof(LzHdr));       // [2][LZ_GMAX][CAP]
+    float *xc4 = reinterpret_cast<float *>(xchg + 64 + 2 * LZ_GMAX * sizeof(LzHdr));         // [2][LZ_GMAX][CAP][4]
     unsigned *xlo = reinterpret_cast<unsigned *>(xchg + 64 + 2 * LZ_GMAX * sizeof(LzHdr) + (size_t)2 * LZ_GMAX * CAP * sizeof(float4));
 
     // samples inherited from the previous call on this state, or verified to be the identity prefix (fps_bucket.hip);
@@ -195,58 +204,54 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
     }
     if (done >= m) return;
 
-    // ---- owned buckets: slot s of lane l  <->  bucket (s*64 + l)*NW + wave; box and largest key in registers ----
-    float mnx[NBL], mny[NBL], mnz[NBL], mxx[NBL], mxy[NBL], mxz[NBL];
-    unsigned long long key[NBL];
-#pragma unroll
-    for (int s = 0; s < NBL; s++) {
-        mnx[s] = mny[s] = mnz[s] = INFINITY;  // an absent bucket is never reached and never holds a candidate
-        mxx[s] = mxy[s] = mxz[s] = -INFINITY;
-        key[s] = 0ull;
-    }
-    for (int t = tid; t < LZ_MAXSB; t += NT) {
+    // ---- owned buckets: register slot sl of this wave <-> local bucket sl * NW + wave; lane <-> point.  The bucket's box and
+    //      largest key live in lane sl. ----
+    float X[NSLOT], Y[NSLOT], Z[NSLOT], W[NSLOT];
+    unsigned R[NSLOT];
+    float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;  // (an absent bucket is never reached)
+    unsigned long long key = 0ull;
+    for (int t = tid; t < NSLOT; t += NT) {
         sbbox[t][0] = sbbox[t][1] = sbbox[t][2] = 0xffffffffu;
         sbbox[t][3] = sbbox[t][4] = sbbox[t][5] = 0u;
         sbmax[0][t] = sbmax[1][t] = 0u;
     }
+    for (int t = tid; t < NSLOT * WORDS; t += NT) sbhit[t / WORDS][t % WORDS] = 0u;
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < NBL; s++) {
-        for (int l = 0; l < 64; l++) {
-            const int li = (s * 64 + l) * NW + wave;
-            if (li >= nbl) break;
-            const int pos = min(start_n + (b0 + li) * 64 + lane, end_n - 1);
+    for (int sl = 0; sl < NSLOT; sl++) {
+        const int li = sl * NW + wave;
+        X[sl] = Y[sl] = Z[sl] = W[sl] = 0.f;
+        R[sl] = 0u;
+        if (li < nbl) {  // wave-uniform
+            const int pos = min(start_n + (b0 + li) * 64 + lane, end_n - 1);  // lanes past the end copy the last point
             const float4 p = pts[pos];
-            float a0 = p.x, a1 = p.y, a2 = p.z, b0 = p.x, b1 = p.y, b2 = p.z;
+            X[sl] = p.x; Y[sl] = p.y; Z[sl] = p.z; W[sl] = p.w;
+            R[sl] = rank[pos];
+            float a0 = p.x, a1 = p.y, a2 = p.z, c0 = p.x, c1 = p.y, c2 = p.z;
             for (int st = 1; st < 64; st <<= 1) {
                 a0 = fminf(a0, __shfl_xor(a0, st, 64)); a1 = fminf(a1, __shfl_xor(a1, st, 64)); a2 = fminf(a2, __shfl_xor(a2, st, 64));
-                b0 = fmaxf(b0, __shfl_xor(b0, st, 64)); b1 = fmaxf(b1, __shfl_xor(b1, st, 64)); b2 = fmaxf(b2, __shfl_xor(b2, st, 64));
+                c0 = fmaxf(c0, __shfl_xor(c0, st, 64)); c1 = fmaxf(c1, __shfl_xor(c1, st, 64)); c2 = fmaxf(c2, __shfl_xor(c2, st, 64));
             }
-            const KeyMax km = wave_key_max(((unsigned long long)__float_as_uint(p.w) << 32) | rank[pos]);
-            if (lane == l) {
-                mnx[s] = a0; mny[s] = a1; mnz[s] = a2; mxx[s] = b0; mxy[s] = b1; mxz[s] = b2;
-                key[s] = km.key;
+            const KeyMax km = wave_key_max(((unsigned long long)__float_as_uint(p.w) << 32) | R[sl]);
+            if (lane == sl) {
+                mnx = a0; mny = a1; mnz = a2; mxx = c0; mxy = c1; mxz = c2;
+                key = km.key;
             }
         }
     }
-#pragma unroll
-    for (int s = 0; s < NBL; s++)
-        if (key[s] != 0ull || mnx[s] != INFINITY) {
-            const int sb = s * 64 + lane;
-            atomicMin(&sbbox[sb][0], ord_bits(mnx[s])); atomicMin(&sbbox[sb][1], ord_bits(mny[s])); atomicMin(&sbbox[sb][2], ord_bits(mnz[s]));
-            atomicMax(&sbbox[sb][3], ord_bits(mxx[s])); atomicMax(&sbbox[sb][4], ord_bits(mxy[s])); atomicMax(&sbbox[sb][5], ord_bits(mxz[s]));
-            atomicMax(&sbmax[0][sb], (unsigned)(key[s] >> 32));
-        }
+    const bool own = lane < NSLOT && lane * NW + wave < nbl;  // this lane holds a bucket's box and key
+    if (own) {
+        atomicMin(&sbbox[lane][0], ord_bits(mnx)); atomicMin(&sbbox[lane][1], ord_bits(mny)); atomicMin(&sbbox[lane][2], ord_bits(mnz));
+        atomicMax(&sbbox[lane][3], ord_bits(mxx)); atomicMax(&sbbox[lane][4], ord_bits(mxy)); atomicMax(&sbbox[lane][5], ord_bits(mxz));
+        atomicMax(&sbmax[0][lane], (unsigned)(key >> 32));
+    }
     if (tid == 0 && done == 0 && g == 0) idx[start_m] = start_n;
-    __syncthreads();  // boxes complete
     // the last selected sample has not been applied to the min-dist field yet (fps_bucket.hip's convention; applying a
     // sample twice is harmless): it is the first round's accepted set
-    {
-        if (tid == 0) {
-            ax[0] = xyz[(size_t)first * 3 + 0];
-            ay[0] = xyz[(size_t)first * 3 + 1];
-            az[0] = xyz[(size_t)first * 3 + 2];
-        }
+    if (tid == 0) {
+        ax[0] = xyz[(size_t)first * 3 + 0];
+        ay[0] = xyz[(size_t)first * 3 + 1];
+        az[0] = xyz[(size_t)first * 3 + 2];
     }
     done = max(done, 1);
     int A = 1;                                   // accepted samples waiting to be applied
@@ -262,107 +267,84 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
         // ================= update: apply the A accepted samples =================
         const int nwA = (A + 31) >> 5;
         if (STAMP) { c_ph[12] += 1; c_ph[13] += A; }
-        // (1) sample x super-bucket box tests -> sbhit; one (super-bucket, 32 samples) unit per thread trip
-        for (int u = tid; u < nsb * nwA; u += NT) {
-            const int sb = u / nwA, w = u - sb * nwA;
-            const float bx0 = ord_float(sbbox[sb][0]), by0 = ord_float(sbbox[sb][1]), bz0 = ord_float(sbbox[sb][2]);
-            const float bx1 = ord_float(sbbox[sb][3]), by1 = ord_float(sbbox[sb][4]), bz1 = ord_float(sbbox[sb][5]);
-            const float dmax = __uint_as_float(sbmax[buf][sb]);
-            unsigned bits = 0u;
-            const int a0 = w * 32, a1 = min(A, a0 + 32);
-            for (int a = a0; a < a1; a++)
-                if (box_lb(ax[a], ay[a], az[a], bx0, by0, bz0, bx1, by1, bz1) < dmax) bits |= 1u << (a - a0);
-            sbhit[sb][w] = bits;
+        // (1) sample x super-bucket box tests -> sbhit (zero on entry); one (super-bucket, 8 samples) unit per thread trip
+        {
+            const int nu8 = (A + 7) >> 3;
+            for (int u = tid; u < nsb * nu8; u += NT) {
+                const int sb = u / nu8, w8 = u - sb * nu8;
+                const float bx0 = ord_float(sbbox[sb][0]), by0 = ord_float(sbbox[sb][1]), bz0 = ord_float(sbbox[sb][2]);
+                const float bx1 = ord_float(sbbox[sb][3]), by1 = ord_float(sbbox[sb][4]), bz1 = ord_float(sbbox[sb][5]);
+                const float dmax = __uint_as_float(sbmax[buf][sb]);
+                unsigned bits = 0u;
+                const int a0 = w8 * 8, a1 = min(A, a0 + 8);
+                for (int a = a0; a < a1; a++)
+                    if (box_lb(ax[a], ay[a], az[a], bx0, by0, bz0, bx1, by1, bz1) < dmax) bits |= 1u << (a & 31);
+                if (bits) atomicOr(&sbhit[sb][a0 >> 5], bits);
+            }
         }
-        for (int t = tid; t < LZ_MAXSB; t += NT) sbmax[buf ^ 1][t] = 0u;
+        if (tid < NSLOT) sbmax[buf ^ 1][tid] = 0u;
         __syncthreads();
         stamp(1);  // 1: sample x super-bucket tests
-        // (2) every lane: which of those samples reach its own buckets (up to four ids kept; more: all of the super-bucket's)
-        unsigned long long lst[NBL];
-        int cntl[NBL];
-#pragma unroll
-        for (int s = 0; s < NBL; s++) {
-            lst[s] = 0ull;
-            cntl[s] = 0;
-            const int sb = s * 64 + lane;
-            if (sb < nsb && mnx[s] != INFINITY) {
-                const float dmax = __uint_as_float((unsigned)(key[s] >> 32));
-                for (int w = 0; w < nwA; w++) {
-                    unsigned bits = sbhit[sb][w];
-                    while (bits) {
-                        const int a = w * 32 + __ffs(bits) - 1;
-                        bits &= bits - 1;
-                        if (box_lb(ax[a], ay[a], az[a], mnx[s], mny[s], mnz[s], mxx[s], mxy[s], mxz[s]) < dmax) {
-                            if (cntl[s] < 4) lst[s] |= (unsigned long long)a << (16 * cntl[s]);
-                            cntl[s]++;
-                        }
+        // (2) lane sl: which of those samples reach its bucket (up to four ids kept; more: all of the super-bucket's)
+        unsigned long long lst = 0ull;
+        int cntl = 0;
+        if (own) {
+            const float dmax = __uint_as_float((unsigned)(key >> 32));
+            for (int w = 0; w < nwA; w++) {
+                unsigned bits = sbhit[lane][w];
+                while (bits) {
+                    const int a = w * 32 + __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    if (box_lb(ax[a], ay[a], az[a], mnx, mny, mnz, mxx, mxy, mxz) < dmax) {
+                        if (cntl < 4) lst |= (unsigned long long)a << (16 * cntl);
+                        cntl++;
                     }
                 }
             }
         }
         stamp(2);  // 2: own-bucket tests
-        // (3) the wave updates its touched buckets: 64 lanes <-> 64 points, the loads of up to four buckets in flight together
+        // (3) the wave updates its touched buckets in registers
+        {
+            const unsigned touched = (unsigned)__ballot(cntl > 0);  // (bits = slots, wave-uniform)
 #pragma unroll
-        for (int s = 0; s < NBL; s++) {
-            unsigned long long touched = __ballot(cntl[s] > 0);
-            while (touched) {
-                int ol[4], pos[4];
-                float4 p[4];
-                unsigned rk[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    ol[u] = touched ? __ffsll(touched) - 1 : -1;  // wave-uniform
-                    touched &= touched - 1;                       // (0 & anything stays 0)
-                    pos[u] = min(start_n + (b0 + (s * 64 + max(ol[u], 0)) * NW + wave) * 64 + lane, end_n - 1);  // lanes past the end copy the last point
-                    if (ol[u] >= 0) { p[u] = pts[pos[u]]; rk[u] = rank[pos[u]]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (ol[u] < 0) continue;  // wave-uniform
-                    const int c = __builtin_amdgcn_readlane(cntl[s], ol[u]);
-                    const unsigned l0 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)lst[s], ol[u]);
-                    const unsigned l1 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(lst[s] >> 32), ol[u]);
-                    float d2 = p[u].w;
-                    if (c <= 4) {
-                        const unsigned long long ids = ((unsigned long long)l1 << 32) | l0;
-                        for (int v = 0; v < c; v++) {
-                            const int a = (int)((ids >> (16 * v)) & 0xffffu);
-                            d2 = fminf(d2, sqd(p[u].x - ax[a], p[u].y - ay[a], p[u].z - az[a]));
-                        }
-                    } else {
-                        const int sb = s * 64 + ol[u];
-                        for (int w = 0; w < nwA; w++) {
-                            unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane((int)sbhit[sb][w]);
-                            while (bits) {
-                                const int a = w * 32 + __ffs(bits) - 1;
-                                bits &= bits - 1;
-                                d2 = fminf(d2, sqd(p[u].x - ax[a], p[u].y - ay[a], p[u].z - az[a]));
-                            }
+            for (int sl = 0; sl < NSLOT; sl++) {
+                if (!((touched >> sl) & 1u)) continue;
+                const int c = __builtin_amdgcn_readlane(cntl, sl);
+                const unsigned long long ids = readlane64(lst, sl);
+                float d2 = W[sl];
+                if (c <= 4) {
+                    for (int v = 0; v < c; v++) {
+                        const int a = (int)((ids >> (16 * v)) & 0xffffu);
+                        d2 = fminf(d2, sqd(X[sl] - ax[a], Y[sl] - ay[a], Z[sl] - az[a]));
+                    }
+                } else {
+                    for (int w = 0; w < nwA; w++) {
+                        unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane((int)sbhit[sl][w]);
+                        while (bits) {
+                            const int a = w * 32 + __ffs(bits) - 1;
+                            bits &= bits - 1;
+                            d2 = fminf(d2, sqd(X[sl] - ax[a], Y[sl] - ay[a], Z[sl] - az[a]));
                         }
                     }
-                    reinterpret_cast<float *>(pts + pos[u])[3] = d2;
-                    const KeyMax km = wave_key_max(((unsigned long long)__float_as_uint(d2) << 32) | rk[u]);
-                    if (lane == ol[u]) key[s] = km.key;
                 }
+                W[sl] = d2;
+                const KeyMax km = wave_key_max(((unsigned long long)__float_as_uint(d2) << 32) | R[sl]);
+                if (lane == sl) key = km.key;
             }
         }
         stamp(3);  // 3: bucket updates
         // ================= select =================
         {
-            unsigned long long mk = key[0];
-#pragma unroll
-            for (int s = 1; s < NBL; s++) mk = key[s] > mk ? key[s] : mk;
-            const KeyMax wm = wave_key_max(mk);
+            const KeyMax wm = wave_key_max(own ? key : 0ull);
             if (lane == 0) wkey[wave] = wm.key;
-#pragma unroll
-            for (int s = 0; s < NBL; s++)
-                if (mnx[s] != INFINITY) atomicMax(&sbmax[buf ^ 1][s * 64 + lane], (unsigned)(key[s] >> 32));
+            if (own) atomicMax(&sbmax[buf ^ 1][lane], (unsigned)(key >> 32));
         }
         buf ^= 1;
         if (tid == 0) { s_cnt = 0; s_tover = 0ull; s_tdrop = 0ull; s_nacc = 0; s_changed[0] = 0; s_changed[1] = 0; }
-        if (tid < 3) s_org[tid] = 0xffffffffu;
         for (int t = tid; t < LZ_GRID; t += NT) ghead[t] = -1;
+        for (int t = tid; t < CAP; t += NT) hcnt[t] = 0;
         __syncthreads();
+        for (int t = tid; t < NSLOT * WORDS; t += NT) sbhit[t / WORDS][t % WORDS] = 0u;  // (last read above; written again after more barriers)
         stamp(4);  // 4: maxima + barrier (waiting for the slowest wave's updates)
         if (done >= m) break;  // (uniform, and the same in every workgroup) everything selected, and applied
         unsigned long long ltop = 0ull;  // this workgroup's largest key
@@ -375,40 +357,26 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
         const float tau = fmaxf(bnd * (1.0f - frac), 0.f);
         const unsigned taub = __float_as_uint(tau);
         {
-            float4 *my4 = xc4 + ((size_t)par * LZ_GMAX + g) * CAP;
+            float *my4 = xc4 + ((size_t)par * LZ_GMAX + g) * CAP * 4;
             unsigned *mylo = xlo + ((size_t)par * LZ_GMAX + g) * CAP;
+            const unsigned have = (unsigned)__ballot(own && (unsigned)(key >> 32) >= taub);
 #pragma unroll
-            for (int s = 0; s < NBL; s++) {
-                unsigned long long have = __ballot(mnx[s] != INFINITY && (unsigned)(key[s] >> 32) >= taub);
-                while (have) {
-                    int ol[4], pos[4];
-                    float4 p[4];
-                    unsigned rk[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        ol[u] = have ? __ffsll(have) - 1 : -1;
-                        have &= have - 1;
-                        pos[u] = start_n + (b0 + (s * 64 + max(ol[u], 0)) * NW + wave) * 64 + lane;
-                        if (ol[u] >= 0) { p[u] = pts[min(pos[u], end_n - 1)]; rk[u] = rank[min(pos[u], end_n - 1)]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (ol[u] < 0) continue;  // wave-uniform
-                        const bool cand = pos[u] < end_n && __float_as_uint(p[u].w) >= taub;
-                        const unsigned long long cm = __ballot(cand);
-                        if (cm) {
-                            int base = 0;
-                            if (lane == 0) base = atomicAdd(&s_cnt, __popcll(cm));
-                            base = __builtin_amdgcn_readfirstlane(base);
-                            if (cand) {
-                                const int at = base + __popcll(cm & ((1ull << lane) - 1ull));
-                                if (at < CAP) {
-                                    my4[at] = p[u];
-                                    mylo[at] = rk[u];
-                                } else {
-                                    atomicMax(&s_tover, ((unsigned long long)__float_as_uint(p[u].w) << 32) | rk[u]);
-                                }
-                            }
+            for (int sl = 0; sl < NSLOT; sl++) {
+                if (!((have >> sl) & 1u)) continue;
+                const bool cand = start_n + (b0 + sl * NW + wave) * 64 + lane < end_n && __float_as_uint(W[sl]) >= taub;
+                const unsigned long long cm = __ballot(cand);
+                if (cm) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_cnt, __popcll(cm));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (cand) {
+                        const int at = base + __popcll(cm & ((1ull << lane) - 1ull));
+                        if (at < CAP) {
+                            st_agent(my4 + at * 4 + 0, X[sl]); st_agent(my4 + at * 4 + 1, Y[sl]);
+                            st_agent(my4 + at * 4 + 2, Z[sl]); st_agent(my4 + at * 4 + 3, W[sl]);
+                            st_agent(mylo + at, R[sl]);
+                        } else {
+                            atomicMax(&s_tover, ((unsigned long long)__float_as_uint(W[sl]) << 32) | R[sl]);
                         }
                     }
                 }
@@ -425,39 +393,49 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
         round++;
         if (!group_barrier(bar, round * (unsigned)G, G, &s_abort)) return;  // (uniform in the workgroup; see LZ_PATIENCE)
         stamp(10);  // 10: waiting for the other workgroups
-        // ---- everybody reads everybody's list (in workgroup order, cut at CAP: what is cut is bounded by its workgroup's top) ----
+        // ---- everybody reads everybody's list (in workgroup order, cut at CAP: what is cut is bounded by its workgroup's top).
+        //      One trip: lane q of every wave fetches header q while the wave fetches - speculatively - entries of "its" workgroup ----
         int K = 0, found = 0;
         unsigned long long gtop = 0ull, tover = 0ull;
-        int gbase[LZ_GMAX + 1];
-#pragma unroll
-        for (int gg = 0; gg < LZ_GMAX; gg++) {
-            gbase[gg] = K;
-            if (gg < G) {
-                const LzHdr *h = hdr + par * LZ_GMAX + gg;
-                const unsigned long long tp = ld_agent(&h->top), tv = ld_agent(&h->tover);
-                const int c = ld_agent(&h->count);
+        {
+            const int E = NT / G;                       // list entries a pass covers per workgroup (>= 64; G divides NT)
+            const int gg = tid / E, e0 = tid - gg * E;  // (gg is wave-uniform)
+            unsigned long long h_top = 0ull, h_tov = 0ull;
+            int h_cnt = 0;
+            if (lane < G) {
+                const LzHdr *h = hdr + par * LZ_GMAX + lane;
+                h_top = ld_agent(&h->top); h_tov = ld_agent(&h->tover); h_cnt = ld_agent(&h->count);
+            }
+            const size_t seg = ((size_t)par * LZ_GMAX + gg) * CAP;
+            float sx = 0.f, sy = 0.f, sz = 0.f, sd = 0.f;
+            unsigned slo = 0u;
+            if (e0 < CAP) {
+                sx = ld_agent(xc4 + (seg + e0) * 4 + 0); sy = ld_agent(xc4 + (seg + e0) * 4 + 1); sz = ld_agent(xc4 + (seg + e0) * 4 + 2);
+                sd = ld_agent(xc4 + (seg + e0) * 4 + 3);
+                slo = ld_agent(xlo + seg + e0);
+            }
+            int mybase = 0, mytake = 0, maxtake = 0;
+            for (int q = 0; q < G; q++) {  // (uniform)
+                const int c = __builtin_amdgcn_readlane(h_cnt, q);
+                const unsigned long long tp = readlane64(h_top, q), tv = readlane64(h_tov, q);
                 found += c;
                 gtop = tp > gtop ? tp : gtop;
                 tover = tv > tover ? tv : tover;
                 const int keep = min(c, CAP), take = min(keep, CAP - K);
                 if (take < keep) tover = tp > tover ? tp : tover;
+                if (q == gg) { mybase = K; mytake = take; }
+                maxtake = max(maxtake, take);
                 K += take;
             }
-        }
-        gbase[LZ_GMAX] = K;
-        for (int t = tid; t < K; t += NT) {
-            int gg = 0;
-#pragma unroll
-            for (int q = 1; q < LZ_GMAX; q++) gg += (q < G && t >= gbase[q]) ? 1 : 0;
-            int gb = 0;
-#pragma unroll
-            for (int q = 0; q < LZ_GMAX; q++) gb = q == gg ? gbase[q] : gb;
-            const size_t at = ((size_t)par * LZ_GMAX + gg) * CAP + (t - gb);
-            const float *src = reinterpret_cast<const float *>(xc4 + at);
-            const float x = ld_agent(src + 0), y = ld_agent(src + 1), z = ld_agent(src + 2), d = ld_agent(src + 3);
-            cx[t] = x; cy[t] = y; cz[t] = z; cd[t] = d;
-            clo[t] = ld_agent(xlo + at);
-            atomicMin(&s_org[0], ord_bits(x)); atomicMin(&s_org[1], ord_bits(y)); atomicMin(&s_org[2], ord_bits(z));
+            for (int e = e0;; e += E) {
+                if (e < mytake) { cx[mybase + e] = sx; cy[mybase + e] = sy; cz[mybase + e] = sz; cd[mybase + e] = sd; clo[mybase + e] = slo; }
+                if (e - e0 + E >= maxtake) break;  // (uniform) nobody's list is longer than what the passes so far covered
+                if (e + E < mytake) {
+                    sx = ld_agent(xc4 + (seg + e + E) * 4 + 0); sy = ld_agent(xc4 + (seg + e + E) * 4 + 1); sz = ld_agent(xc4 + (seg + e + E) * 4 + 2);
+                    sd = ld_agent(xc4 + (seg + e + E) * 4 + 3);
+                    slo = ld_agent(xlo + seg + e + E);
+                }
+            }
         }
         const float dtop = __uint_as_float((unsigned)(gtop >> 32));
         {
@@ -491,51 +469,67 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
                 __syncthreads();
             }
         stamp(6);  // 6: sort
-        // ---- hitters through a hash grid.  hit(r, r2) = r2 < r (larger key) && d(r2, r) < d_r needs |p_r - p_r2| < sqrt(d_top) per
-        //      axis: with cells of that edge (plus slack for the rounding of the cell index) only the 27 cells around a
-        //      candidate can hold a hitter ----
-        const float cell = sqrtf(dtop) * 1.002f + 1e-30f, inv_cell = 1.0f / cell;
-        const float ox = ord_float(s_org[0]), oy = ord_float(s_org[1]), oz = ord_float(s_org[2]);
+        // ---- hitters.  hit(r, r2) = r2 < r (larger key) && d(r2, r) < d_r.  Few candidates: all pairs, spread over the whole
+        //      workgroup.  Many: a hash grid - a hit needs |p_r - p_r2| < sqrt(d_top) per axis, so with cells of that edge (plus
+        //      slack for the rounding of the cell index; cell indices wrap at 1024, which only merges cells) only the 27 cells
+        //      around a candidate can hold a hitter; the 27 cells of a candidate are split over the threads that share it ----
         float px = 0.f, py = 0.f, pz = 0.f, pd = 0.f;
-        int gx = 0, gy = 0, gz = 0;
-        auto cell_hash = [](int x, int y, int z) -> unsigned {
-            return ((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (LZ_GRID - 1);
-        };
         if (tid < K) {
             const int c = sidx[tid];
             px = cx[c]; py = cy[c]; pz = cz[c]; pd = cd[c];
-            gx = min(max((int)floorf((px - ox) * inv_cell), 0), 1022);  // (clamped cells only merge: still a superset)
-            gy = min(max((int)floorf((py - oy) * inv_cell), 0), 1022);
-            gz = min(max((int)floorf((pz - oz) * inv_cell), 0), 1022);
-            ccell[tid] = (unsigned)gx | ((unsigned)gy << 10) | ((unsigned)gz << 20);
             sp4[tid] = make_float4(px, py, pz, pd);
-            gnext[tid] = (short)atomicExch(&ghead[cell_hash(gx, gy, gz)], tid);
         }
-        __syncthreads();
-        int nh = 0;
-        if (tid < K) {
-            for (int dz = -1; dz <= 1; dz++)
-                for (int dy = -1; dy <= 1; dy++)
-                    for (int dx = -1; dx <= 1; dx++) {
-                        const int qx = gx + dx, qy = gy + dy, qz = gz + dz;
-                        if (qx < 0 || qy < 0 || qz < 0) continue;
-                        const unsigned want = (unsigned)qx | ((unsigned)qy << 10) | ((unsigned)qz << 20);
-                        for (int r2 = ghead[cell_hash(qx, qy, qz)]; r2 >= 0; r2 = gnext[r2]) {
-                            if (r2 >= tid || ccell[r2] != want) continue;  // smaller key, or another cell of the same hash chain
-                            const float4 q = sp4[r2];
-                            if (sqd(px - q.x, py - q.y, pz - q.z) < pd) {
-                                if (nh < LZ_HITS) hl[tid][nh] = (unsigned short)r2;
-                                nh++;
-                            }
-                        }
+        if (K <= LZ_PAIRS_MAX) {
+            __syncthreads();
+            const int j = tid & (LZ_PAIRS_MAX - 1), part = tid / LZ_PAIRS_MAX;  // NT / PAIRS_MAX = 8 threads share candidate j
+            if (j < K) {
+                const float4 me = sp4[j];
+                for (int r2 = part; r2 < j; r2 += NT / LZ_PAIRS_MAX) {
+                    const float4 q = sp4[r2];
+                    if (sqd(me.x - q.x, me.y - q.y, me.z - q.z) < me.w) {
+                        const int at = atomicAdd(&hcnt[j], 1);
+                        if (at < LZ_HITS) hl[j][at] = (unsigned short)r2;
                     }
-            hcnt[tid] = (unsigned char)min(nh, 255);
+                }
+            }
+        } else {
+            const float cell = sqrtf(dtop) * 1.002f + 1e-30f, inv_cell = 1.0f / cell;
+            if (tid < K) {
+                const int gx = (int)floorf(px * inv_cell) & 1023;
+                const int gy = (int)floorf(py * inv_cell) & 1023;
+                const int gz = (int)floorf(pz * inv_cell) & 1023;
+                ccell[tid] = (unsigned)gx | ((unsigned)gy << 10) | ((unsigned)gz << 20);
+                gnext[tid] = (short)atomicExch(&ghead[cell_hash(gx, gy, gz)], tid);
+            }
+            __syncthreads();
+            const int KP = (K + 63) & ~63, S = NT / KP;  // S = 2 ... 5 threads share a candidate (K > 128)
+            const int part = tid / KP, j = tid - part * KP;
+            if (part < S && j < K) {
+                const float4 me = sp4[j];
+                const unsigned cc = ccell[j];
+                const int jx = cc & 1023, jy = (cc >> 10) & 1023, jz = cc >> 20;
+                for (int c9 = part; c9 < 27; c9 += S) {
+                    const int qx = (jx + c9 % 3 - 1) & 1023, qy = (jy + (c9 / 3) % 3 - 1) & 1023, qz = (jz + c9 / 9 - 1) & 1023;
+                    const unsigned want = (unsigned)qx | ((unsigned)qy << 10) | ((unsigned)qz << 20);
+                    for (int r2 = ghead[cell_hash(qx, qy, qz)]; r2 >= 0;) {
+                        const unsigned oc = ccell[r2];
+                        const float4 q = sp4[r2];
+                        const int nx = gnext[r2];
+                        if (r2 < j && oc == want && sqd(me.x - q.x, me.y - q.y, me.z - q.z) < me.w) {
+                            const int at = atomicAdd(&hcnt[j], 1);
+                            if (at < LZ_HITS) hl[j][at] = (unsigned short)r2;
+                        }
+                        r2 = nx;
+                    }
+                }
+            }
         }
         if (tid < WORDS) {
             const int lo = tid * 32;
             accw[0][tid] = K >= lo + 32 ? 0xffffffffu : (K > lo ? ((1u << (K - lo)) - 1u) : 0u);
         }
         __syncthreads();
+        const int nh = tid < K ? hcnt[tid] : 0;
         stamp(7);  // 7: hitters
         // ---- resolve: fixed point of acc_r = !exists r2 in hitters(r): acc_r2  (a candidate with more hitters than the list holds
         //      is simply not decided in this round) ----
@@ -628,46 +622,80 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, co
             bnd = dtop;
             __syncthreads();
         }
+        if (STAMP && dbg && tid == 0 && g == 0 && round <= 512) dbg[14 + round - 1] = ((unsigned long long)found << 40) | ((unsigned long long)lastK << 20) | (unsigned)A;
         done += A;
         stamp(9);  // 9: bounds, ranks, output
+    }
+    // the state a resumed call (or fps_bucket.hip) continues from
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; sl++) {
+        const int pos = start_n + (b0 + sl * NW + wave) * 64 + lane;
+        if (sl * NW + wave < nbl && pos < end_n) reinterpret_cast<float *>(pts + pos)[3] = W[sl];
     }
     if (STAMP && dbg && tid == 0 && g == 0)
         for (int i = 0; i < 14; i++) dbg[bid * 14 + i] = c_ph[i];
 }
 
-// workgroups per batch element: a workgroup should own ~100+ buckets for its share of a round to outweigh the barrier;
-// all b * G workgroups must be resident together (they wait for each other), so large batches get fewer
-static int lz_groups(int b, int n_max) {
+// Workgroups per batch element: enough that a workgroup's buckets fit its registers (NW * NSLOT), and about a hundred
+// buckets each beyond that (more workgroups = less to do per round for each; the barrier costs the same).  0: the cloud is
+// too large for this kernel.
+int fps_lazy_groups(int n_max) {
     static const int env = getenv("P2_FPS_GROUPS") ? atoi(getenv("P2_FPS_GROUPS")) : 0;
-    const int nb = (n_max + 63) / 64;
-    int G = env > 0 ? env : nb / 96;
-    G = std::max(1, std::min(G, LZ_GMAX));
-    while (G > 1 && b * G > 64) G--;
+    const int nb = (n_max + 63) / 64, cap = LZ_NW * LZ_NSLOT;
+    const int need = (nb + cap - 1) / cap;
+    if (need > LZ_GMAX) return 0;
+    int G = env > 0 ? env : (nb + 99) / 100;
+    G = std::max(std::max(need, 1), std::min(G, LZ_GMAX));
+    while (G < LZ_GMAX && LZ_NT % G != 0) G++;  // the list readers want G to divide the workgroup: 1, 2, 4, 8, 16
     return G;
 }
 
 void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, const int *offset, const int *new_offset, float4 *pts, const unsigned *rank,
                      const int *prev_idx, const int *prev_offset, const int *verified, int *idx, void *xchg, hipStream_t st) {
-    allow_big_lds(fps_lazy_kernel<false>, lz_lds_bytes());
-    allow_big_lds(fps_lazy_kernel<true>, lz_lds_bytes());
-    const int G = lz_groups(b, n_max);
-    (void)hipMemsetAsync(xchg, 0, (size_t)b * LZ_XCHG, st);  // barrier counters (and headers)
+    const int G = fps_lazy_groups(n_max);
+    const int slots = div_up(div_up(div_up(n_max, 64), G), LZ_NW);  // register slots a wave needs
+    (void)hipMemsetAsync(xchg, 0, (size_t)b * LZ_XCHG, st);          // barrier counters (and headers)
     if (getenv("P2_FPS_STAMPS")) {  // diagnostic only: synchronous, prints the phase cycles of wave 0 of workgroup 0 to stderr
-        unsigned long long *dbg = nullptr, host[14];
+        unsigned long long *dbg = nullptr, host[14 + 512];  // (per-round trace of batch element 0 only)
         (void)hipMalloc(&dbg, sizeof(host) * b);
         (void)hipMemset(dbg, 0, sizeof(host) * b);
-        hipLaunchKernelGGL(fps_lazy_kernel<true>, dim3(G, b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
-                           verified, idx, (unsigned char *)xchg, dbg);
+        if (slots <= 8) {
+            allow_big_lds(fps_lazy_kernel<true, 8>, lz_lds_bytes());
+            hipLaunchKernelGGL((fps_lazy_kernel<true, 8>), dim3(G, b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, 0, xyz, offset, new_offset, pts, rank, prev_idx,
+                               prev_offset, verified, idx, (unsigned char *)xchg, dbg);
+        } else {
+            allow_big_lds(fps_lazy_kernel<true, LZ_NSLOT>, lz_lds_bytes());
+            hipLaunchKernelGGL((fps_lazy_kernel<true, LZ_NSLOT>), dim3(G, b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, 0, xyz, offset, new_offset, pts, rank, prev_idx,
+                               prev_offset, verified, idx, (unsigned char *)xchg, dbg);
+        }
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
         (void)hipFree(dbg);
-        fprintf(stderr, "[fps lazy] G %d rounds %llu samples %llu | cycles: setup %llu sbtests %llu owntests %llu updates %llu maxima+wait %llu gather %llu gridwait %llu "
-                        "lists %llu sort %llu hitters %llu fixedpoint %llu output %llu\n", G, host[12], host[13], host[0], host[1], host[2], host[3], host[4], host[5],
+        fprintf(stderr, "[fps lazy] G %d slots %d rounds %llu samples %llu | cycles: setup %llu sbtests %llu owntests %llu updates %llu maxima+wait %llu gather %llu gridwait %llu "
+                        "lists %llu sort %llu hitters %llu fixedpoint %llu output %llu\n", G, slots, host[12], host[13], host[0], host[1], host[2], host[3], host[4], host[5],
                 host[10], host[11], host[6], host[7], host[8], host[9]);
+        if (getenv("P2_FPS_TRACE_ROUNDS")) {
+            fprintf(stderr, "[fps lazy] found/listed/accepted per round:");
+            for (int i = 0; i < 512 && host[14 + i]; i++)
+                fprintf(stderr, " %llu/%llu/%llu", host[14 + i] >> 40, (host[14 + i] >> 20) & 0xfffff, host[14 + i] & 0xfffff);
+            fprintf(stderr, "\n");
+        }
         return;
     }
-    hipLaunchKernelGGL(fps_lazy_kernel<false>, dim3(G, b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, xyz, offset, new_offset, pts, rank, prev_idx, prev_offset,
-                       verified, idx, (unsigned char *)xchg, (unsigned long long *)nullptr);
+    // the workgroups of an element wait for each other: all of a launch must be resident together -> at most 128 per launch
+    const int chunk = std::max(1, 128 / G);
+    for (int c0 = 0; c0 < b; c0 += chunk) {
+        const dim3 grid(G, std::min(chunk, b - c0));
+        if (slots <= 8) {
+            allow_big_lds(fps_lazy_kernel<false, 8>, lz_lds_bytes());
+            hipLaunchKernelGGL((fps_lazy_kernel<false, 8>), grid, dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, c0, xyz, offset, new_offset, pts, rank, prev_idx,
+                               prev_offset, verified, idx, (unsigned char *)xchg, (unsigned long long *)nullptr);
+        } else {
+            allow_big_lds(fps_lazy_kernel<false, LZ_NSLOT>, lz_lds_bytes());
+            hipLaunchKernelGGL((fps_lazy_kernel<false, LZ_NSLOT>), grid, dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, c0, xyz, offset, new_offset, pts, rank, prev_idx,
+                               prev_offset, verified, idx, (unsigned char *)xchg, (unsigned long long *)nullptr);
+        }
+    }
 }
 
 }  // namespace p2

@@ -24,6 +24,7 @@
 // Cells with more than 16 * CA_NP keys are taken in chunks (a running max / sum per query in `ml`, logits parked
 // in pbuf); the shipped configs never need more than one chunk.
 #include "rpe_common.h"
+#include <cstdlib>
 
 namespace p2 {
 
@@ -850,7 +851,13 @@ static int cell_grid_x(K kernel, size_t lds, int tasks, int h, int waves = CA_WA
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), waves * 64, lds) != hipSuccess || per_cu <= 0)
         per_cu = 1;
-    const int cap = max(1, per_cu * device_cus() / max(h, 1));
+    // A few CUs are left to whatever runs beside the blocks (the round sampler holds 16 CUs for milliseconds, kNN and the
+    // index build come and go): tasks are dealt by position, so a workgroup that has to WAIT for a CU serves its whole share
+    // late and the kernel takes twice as long, while leaving 1/16 of the chip idle costs 1/16.  (A work queue - every further
+    // task from a device-scope counter - was measured: the contended atomics cost more than the imbalance.)
+    static const int reserve = getenv("P2_CELL_RESERVE_CUS") ? atoi(getenv("P2_CELL_RESERVE_CUS")) : 0;  // (measured 0 / 16 / 32 / 48: no difference beyond noise, so nothing is reserved)
+    const int cus = max(device_cus() - max(reserve, 0), device_cus() / 2);
+    const int cap = max(1, per_cu * cus / max(h, 1));
     return max(1, min(cap, div_up(tasks, waves)));
 }
 

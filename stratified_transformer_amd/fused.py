@@ -138,8 +138,11 @@ class CellAttention(Function):
         gsbuf = torch.empty_like(pbuf)
         f32 = dict(dtype=torch.float32, device=dev)
         grad_q = torch.empty(q.shape, **f32)
-        grad_k, grad_v = torch.zeros(k.shape, **f32), torch.zeros(v.shape, **f32)
-        gtq, gtk, gtv = torch.zeros(table_q.shape, **f32), torch.zeros(table_k.shape, **f32), torch.zeros(table_v.shape, **f32)
+        # the five accumulated gradients are views of ONE zero-filled buffer: one fill kernel instead of five per block
+        nkv, ntab = k.numel(), table_q.numel()
+        acc = torch.zeros(2 * nkv + 3 * ntab, **f32)
+        grad_k, grad_v = acc[:nkv].view(k.shape), acc[nkv:2 * nkv].view(v.shape)
+        gtq, gtk, gtv = (acc[2 * nkv + i * ntab:2 * nkv + (i + 1) * ntab].view(table_q.shape) for i in range(3))
         _lib.call("cell_attention_backward_launcher" if q.dtype == torch.float32 else "cell_attention_backward_bf16_launcher", plan.c_arg(), h, hdim, L, ptr(grad_out), ptr(q), ptr(k), ptr(v), ptr(out), ptr(table_q),
                   ptr(table_k), ptr(table_v), ptr(pbuf), ptr(gsbuf), ptr(grad_q), ptr(grad_k), ptr(grad_v), ptr(gtq), ptr(gtk), ptr(gtv),
                   device=dev)

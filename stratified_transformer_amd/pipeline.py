@@ -178,6 +178,45 @@ def geometry_stream(device, which=0):
     return _GEO_STREAMS[key]
 
 
+INDEX_THREAD = os.environ.get("P2_INDEX_THREAD", "0") == "1"  # measured: 16.2 ms against 15.5 ms per pass (the two host threads contend), so opt-in
+
+
+class _IndexBuilder:
+    """Runs index(si) for every stage, in order, on a helper thread; wait(si) returns when stage si's index is enqueued
+    (its tensors exist, its event is recorded) and re-raises what the build raised."""
+
+    def __init__(self, index_fn, stages):
+        import threading
+        self._done = {si: threading.Event() for si in stages}
+        self._error = None
+        dev = torch.cuda.current_device()
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                for si in stages:
+                    index_fn(si)
+                    self._done[si].set()
+            except BaseException as e:  # noqa: BLE001 - handed to the waiting thread
+                self._error = e
+            finally:
+                for ev in self._done.values():
+                    ev.set()
+
+        self._thread = threading.Thread(target=work, name="p2-index-build", daemon=True)
+        self._thread.start()
+
+    def wait(self, si):
+        self._done[si].wait()
+        if self._error is not None:
+            raise self._error
+
+    def join(self):
+        self._thread.join()
+        if self._error is not None:
+            raise self._error
+
+
 def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0, cells=False, shard=None):
     """Runs the whole unit once (both phases of scene_pass_phases back to back).  Returns (states, results)."""
     gen = scene_pass_phases(xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane, cells=cells, shard=shard)
@@ -351,10 +390,17 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     after = yield "geometry queued"
     if after is not None:  # passes_in_flight: the attention blocks of this batch follow those of the previous one
         main.wait_event(after)
-    index(first)
+    # The index builds stop the host twice each (key width, pair count) and each waits for its stage's samples.  They run on a
+    # helper thread (own stream; the library's launch state is thread-local), one stage after the other as the geometry
+    # arrives, so the launches of the attention blocks never wait behind a later stage's sampling.
+    builder = _IndexBuilder(index, stages) if (overlap and INDEX_THREAD) else None
+    if builder is None:
+        index(first)
     for si in stages:
         st = cfg.stages[si]
         x, off, _ = clouds[si]
+        if builder is not None:
+            builder.wait(si)
         even, odd, ev_idx = idx_out[si]
         ds, _, knn_idx = geo_out[si]
         if overlap:
@@ -374,7 +420,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         early = si + 1 in stages and si > first
         for b in range(st.depth):
             out = attention_block(state, even if b % 2 == 0 else odd, timer, False if shard else fused, shard)
-            if early and b == 0:
+            if early and b == 0 and builder is None:
                 index(si + 1)
         results.append(dict(stage=si, n=x.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),
                             even=even, odd=odd, downsample_idx=ds, out=out))
@@ -383,8 +429,10 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
             results[-1]["out_rows"] = (last_blk.shard[0].lo, last_blk.shard[0].hi)
         if knn_idx is not None:
             results[-1]["transition_knn"] = knn_idx
-        if si + 1 in stages and not early:
+        if si + 1 in stages and not early and builder is None:
             index(si + 1)
+    if builder is not None:
+        builder.join()
     if overlap:
         main.wait_stream(geo)
         main.wait_stream(knn_s)

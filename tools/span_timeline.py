@@ -7,17 +7,21 @@ from stratified_transformer_amd import scene, pipeline
 cfg = pipeline.s3dis_config()
 xyz = torch.from_numpy(scene.make_room(100000, 0)).cuda()
 off = torch.tensor([100000], dtype=torch.int32, device='cuda')
-states, _ = pipeline.scene_pass(xyz, off, cfg)
-pipeline.scene_pass(xyz, off, cfg, states)
+FUSED = 'cell' if os.environ.get('SPAN_CELL', '1') == '1' else False
+states, _ = pipeline.scene_pass(xyz, off, cfg, fused=FUSED)
+pipeline.scene_pass(xyz, off, cfg, states, fused=FUSED)
 torch.cuda.synchronize()
 timer = pipeline.Timer(True)
 ref = torch.cuda.Event(enable_timing=True)
 ref.record()
-pipeline.scene_pass(xyz, off, cfg, states, timer)
+import time
+h0 = time.perf_counter()
+pipeline.scene_pass(xyz, off, cfg, states, timer, fused=FUSED)
+h1 = time.perf_counter()
 end = torch.cuda.Event(enable_timing=True)
 end.record()
 torch.cuda.synchronize()
-print('pass %.2f ms' % ref.elapsed_time(end))
+print('pass %.2f ms (host enqueue %.2f ms)' % (ref.elapsed_time(end), (h1 - h0) * 1e3))
 rows = [(ref.elapsed_time(e0), ref.elapsed_time(e1), name) for name, e0, e1 in timer.spans]
 rows.sort()
 cur = None

@@ -305,6 +305,27 @@ def test_fps_scene_sizes(P):
     assert np.array_equal(got, ref.furthestsampling(xyz, np.array([20000], np.int32), np.array([2501], np.int32)))
 
 
+def test_fps_ragged_batch_over_many_workgroups(P):
+    """The round sampler with 16 workgroups per cloud (the largest cloud decides), clouds of very different sizes in one batch
+    (workgroups without buckets, a cloud smaller than one bucket, an empty request), more batch elements than one launch holds
+    (two launches), the step-by-step head, and a resumed second call: every index equals the oracle's."""
+    from stratified_transformer_amd import scene
+    sizes = [60000, 3000, 45000, 40, 52000, 9000, 64, 30000, 2049, 58000]
+    pts = [scene.make_room(n, 20 + i) if n >= 2049 else np.random.default_rng(i).random((n, 3), dtype=np.float32) for i, n in enumerate(sizes)]
+    xyz = np.concatenate(pts).astype(np.float32)
+    offset = np.cumsum(sizes).astype(np.int32)
+    m1 = [n // 32 + 1 for n in sizes]
+    m1[3] = 0  # nothing asked of the tiny cloud in the first call
+    m2 = [n // 16 + 1 for n in sizes]
+    no1, no2 = np.cumsum(m1).astype(np.int32), np.cumsum(m2).astype(np.int32)
+    x, off = dev(xyz), dev(offset)
+    P.clear_caches()
+    a = _np(P.furthestsampling(x, off, dev(no1)))
+    b = _np(P.furthestsampling(x, off, dev(no2)))  # resumed from the first call's state
+    assert np.array_equal(b, ref.furthestsampling(xyz, offset, no2))
+    assert np.array_equal(a, ref.furthestsampling(xyz, offset, no1))
+
+
 def _knn(P, k, xyz, new_xyz, offset, new_offset):
     idx, dist = P.knnquery(k, dev(xyz), dev(new_xyz), dev(np.asarray(offset, np.int32)), dev(np.asarray(new_offset, np.int32)))
     return _np(idx), _np(dist)

@@ -43,7 +43,7 @@ constexpr int LZ_NW = 16;
 constexpr int LZ_NT = LZ_NW * 64;
 constexpr int LZ_WORDS = LZ_CAP / 32;
 constexpr int LZ_TARGET = 352;           // candidates the threshold controller aims at (at most)
-constexpr int LZ_GRID = 1024;            // hash cells of the candidate grid
+constexpr int LZ_GRID = 4096;            // hash slots of the candidate grid (1024: every thread walks ~5 foreign entries per round)
 constexpr int LZ_HITS = 8;               // listed hitters per candidate
 constexpr int LZ_PAIRS_MAX = 128;        // up to this many candidates the hitters are found by testing all pairs
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
                                                          const int *__restrict__ prev_offset, const int *__restrict__ verified,
                                                          int *__restrict__ idx, unsigned char *__restrict__ xchg_all,
                                                          unsigned long long *__restrict__ dbg = nullptr) {
-    unsigned long long c_ph[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+    unsigned long long c_ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
     auto stamp = [&](int ph) {
         if (STAMP) {
             __builtin_amdgcn_s_waitcnt(0);
@@ -447,27 +447,41 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
         __syncthreads();
         stamp(11);  // 11: reading the lists
         lastK = K;
-        // ---- sort the candidates by key, descending: sorted position = the order the reference would select them in ----
-        int P2 = 2;
-        while (P2 < K) P2 <<= 1;
-        if (tid < P2) {
-            skey[tid] = tid < K ? (((unsigned long long)__float_as_uint(cd[tid]) << 32) | clo[tid]) : 0ull;
-            sidx[tid] = (unsigned short)tid;
-        }
-        __syncthreads();
-        for (int kk = 2; kk <= P2; kk <<= 1)
-            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                const int other = tid ^ jj;
-                if (tid < P2 && other > tid) {
-                    const unsigned long long a = skey[tid], b = skey[other];
-                    if ((a < b) == ((tid & kk) == 0)) {  // descending overall
-                        skey[tid] = b; skey[other] = a;
-                        const unsigned short t0 = sidx[tid];
-                        sidx[tid] = sidx[other]; sidx[other] = t0;
-                    }
-                }
-                __syncthreads();
+        // ---- order the candidates by key, descending: sorted position = the order the reference would select them in.  Keys are
+        //      unique, so the position of a candidate is the number of larger keys: counted by all threads (NT / KP of them share a
+        //      candidate, each over a contiguous slice of the list; a wave reads the same key at a time: LDS broadcasts) ----
+        {
+            const int KP = max((K + 63) & ~63, 64), S = NT / KP;
+            const int part = tid / KP, j = tid - part * KP;
+            unsigned long long *ukey = reinterpret_cast<unsigned long long *>(sp4);  // (unsorted keys: sp4 is written after the sort)
+            if (tid < K) {
+                ukey[tid] = ((unsigned long long)__float_as_uint(cd[tid]) << 32) | clo[tid];
+                hcnt[tid] = 0;  // (doubles as the position counter; zeroed again below)
             }
+            __syncthreads();
+            if (part < S && j < K) {
+                const unsigned long long mine = ukey[j];
+                const int per = (K + S - 1) / S, i0 = part * per, i1 = min(K, i0 + per);
+                int cnt = 0, i = i0;
+                for (; i + 8 <= i1; i += 8) {  // eight keys in flight: the loop is LDS latency otherwise
+                    unsigned long long kk[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) kk[u] = ukey[i + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) cnt += kk[u] > mine ? 1 : 0;
+                }
+                for (; i < i1; i++) cnt += ukey[i] > mine ? 1 : 0;
+                if (cnt) atomicAdd(&hcnt[j], cnt);
+            }
+            __syncthreads();
+            if (tid < K) {
+                const int pos = hcnt[tid];
+                skey[pos] = ukey[tid];
+                sidx[pos] = (unsigned short)tid;
+            }
+            __syncthreads();
+            if (tid < K) hcnt[tid] = 0;
+        }
         stamp(6);  // 6: sort
         // ---- hitters.  hit(r, r2) = r2 < r (larger key) && d(r2, r) < d_r.  Few candidates: all pairs, spread over the whole
         //      workgroup.  Many: a hash grid - a hit needs |p_r - p_r2| < sqrt(d_top) per axis, so with cells of that edge (plus
@@ -502,16 +516,27 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
                 gnext[tid] = (short)atomicExch(&ghead[cell_hash(gx, gy, gz)], tid);
             }
             __syncthreads();
+            stamp(14);  // 14: grid build (of rounds that use the grid)
             const int KP = (K + 63) & ~63, S = NT / KP;  // S = 2 ... 5 threads share a candidate (K > 128)
             const int part = tid / KP, j = tid - part * KP;
             if (part < S && j < K) {
                 const float4 me = sp4[j];
                 const unsigned cc = ccell[j];
                 const int jx = cc & 1023, jy = (cc >> 10) & 1023, jz = cc >> 20;
-                for (int c9 = part; c9 < 27; c9 += S) {
+                // the heads of all cells of this thread first (independent reads, one latency), then the chains
+                int hd[14];  // (S >= 2: at most 14 of the 27 cells)
+#pragma unroll
+                for (int u = 0; u < 14; u++) {
+                    const int c9 = part + u * S;
+                    const int qx = (jx + c9 % 3 - 1) & 1023, qy = (jy + (c9 / 3) % 3 - 1) & 1023, qz = (jz + c9 / 9 - 1) & 1023;
+                    hd[u] = c9 < 27 ? ghead[cell_hash(qx, qy, qz)] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 14; u++) {
+                    const int c9 = part + u * S;
                     const int qx = (jx + c9 % 3 - 1) & 1023, qy = (jy + (c9 / 3) % 3 - 1) & 1023, qz = (jz + c9 / 9 - 1) & 1023;
                     const unsigned want = (unsigned)qx | ((unsigned)qy << 10) | ((unsigned)qz << 20);
-                    for (int r2 = ghead[cell_hash(qx, qy, qz)]; r2 >= 0;) {
+                    for (int r2 = hd[u]; r2 >= 0;) {
                         const unsigned oc = ccell[r2];
                         const float4 q = sp4[r2];
                         const int nx = gnext[r2];
@@ -523,6 +548,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
                     }
                 }
             }
+            stamp(15);  // 15: grid walk
         }
         if (tid < WORDS) {
             const int lo = tid * 32;
@@ -622,7 +648,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
             bnd = dtop;
             __syncthreads();
         }
-        if (STAMP && dbg && tid == 0 && g == 0 && round <= 512) dbg[14 + round - 1] = ((unsigned long long)found << 40) | ((unsigned long long)lastK << 20) | (unsigned)A;
+        if (STAMP && dbg && tid == 0 && g == 0 && round <= 512) dbg[16 + round - 1] = ((unsigned long long)found << 40) | ((unsigned long long)lastK << 20) | (unsigned)A;
         done += A;
         stamp(9);  // 9: bounds, ranks, output
     }
@@ -633,7 +659,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
         if (sl * NW + wave < nbl && pos < end_n) reinterpret_cast<float *>(pts + pos)[3] = W[sl];
     }
     if (STAMP && dbg && tid == 0 && g == 0)
-        for (int i = 0; i < 14; i++) dbg[bid * 14 + i] = c_ph[i];
+        for (int i = 0; i < 16; i++) dbg[bid * 16 + i] = c_ph[i];
 }
 
 // Workgroups per batch element: enough that a workgroup's buckets fit its registers (NW * NSLOT), and about a hundred
@@ -656,7 +682,7 @@ void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, co
     const int slots = div_up(div_up(div_up(n_max, 64), G), LZ_NW);  // register slots a wave needs
     (void)hipMemsetAsync(xchg, 0, (size_t)b * LZ_XCHG, st);          // barrier counters (and headers)
     if (getenv("P2_FPS_STAMPS")) {  // diagnostic only: synchronous, prints the phase cycles of wave 0 of workgroup 0 to stderr
-        unsigned long long *dbg = nullptr, host[14 + 512];  // (per-round trace of batch element 0 only)
+        unsigned long long *dbg = nullptr, host[16 + 512];  // (per-round trace of batch element 0 only)
         (void)hipMalloc(&dbg, sizeof(host) * b);
         (void)hipMemset(dbg, 0, sizeof(host) * b);
         if (slots <= 8) {
@@ -672,12 +698,12 @@ void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, co
         (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
         (void)hipFree(dbg);
         fprintf(stderr, "[fps lazy] G %d slots %d rounds %llu samples %llu | cycles: setup %llu sbtests %llu owntests %llu updates %llu maxima+wait %llu gather %llu gridwait %llu "
-                        "lists %llu sort %llu hitters %llu fixedpoint %llu output %llu\n", G, slots, host[12], host[13], host[0], host[1], host[2], host[3], host[4], host[5],
-                host[10], host[11], host[6], host[7], host[8], host[9]);
+                        "lists %llu sort %llu hitters %llu (grid build %llu walk %llu) fixedpoint %llu output %llu\n", G, slots, host[12], host[13], host[0], host[1], host[2], host[3],
+                host[4], host[5], host[10], host[11], host[6], host[7] + host[14] + host[15], host[14], host[15], host[8], host[9]);
         if (getenv("P2_FPS_TRACE_ROUNDS")) {
             fprintf(stderr, "[fps lazy] found/listed/accepted per round:");
-            for (int i = 0; i < 512 && host[14 + i]; i++)
-                fprintf(stderr, " %llu/%llu/%llu", host[14 + i] >> 40, (host[14 + i] >> 20) & 0xfffff, host[14 + i] & 0xfffff);
+            for (int i = 0; i < 512 && host[16 + i]; i++)
+                fprintf(stderr, " %llu/%llu/%llu", host[16 + i] >> 40, (host[16 + i] >> 20) & 0xfffff, host[16 + i] & 0xfffff);
             fprintf(stderr, "\n");
         }
         return;

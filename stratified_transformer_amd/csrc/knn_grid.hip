@@ -206,6 +206,142 @@ __global__ __launch_bounds__(BS) void knn_grid_kernel(int m, int k, const float 
     }
 }
 
+// Several lanes per query.  The one-thread-per-query kernel above is a chain of dependent steps per candidate (record load,
+// LDS list insertion; 64 unrelated insertion histories per wave), and 25 000 queries are 1.5 waves per CU.  Here LQ = 16 / 32 /
+// 64 lanes share a query (k + 1 <= LQ): the group's best LQ candidates are ONE sorted register per lane (lane i of the group
+// holds the i-th best as a 64-bit key, distance bits << 32 | index: the reference's (distance, index) order), candidates are
+// taken LQ at a time with coalesced record loads (a batch is filled across the short row segments of a shell), a batch that
+// holds nothing better than the (k+1)-th best is dropped after one vote, any other is sorted (bitonic network over lane
+// exchanges) and merged (reverse + half-cleaners).  No LDS, no per-candidate chain; queries x LQ lanes fill the chip.
+// Same shells, same stopping rule, same tie replay as above.
+template <int LQ>
+__device__ __forceinline__ unsigned long long group_exchange(unsigned long long v, int partner_xor) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, partner_xor, LQ), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), partner_xor, LQ);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int LQ>
+__device__ __forceinline__ unsigned long long group_read(unsigned long long v, int src) {
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src, LQ), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src, LQ);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int LQ>
+__global__ __launch_bounds__(256) void knn_lanes_kernel(int m, int k, const float *__restrict__ new_xyz, const int *__restrict__ offset,
+                                                        const int *__restrict__ new_offset, const KnnPlan *__restrict__ plan,
+                                                        const int *__restrict__ cell_start, const float4 *__restrict__ rec,
+                                                        int *__restrict__ idx, float *__restrict__ dist2, int *__restrict__ replay,
+                                                        int *__restrict__ replay_count, const int *__restrict__ qperm) {
+    const int tid = threadIdx.x, sub = tid & (LQ - 1);
+    const int gq = (blockIdx.x * 256 + tid) / LQ;  // the group's query, in cell order (qperm)
+    if (gq >= m) return;                           // (a whole group leaves; exchanges never cross groups)
+    const int pt = qperm[gq];
+    int bt = 0;
+    while (!(pt < new_offset[bt])) bt++;
+    const int start = bt == 0 ? 0 : offset[bt - 1];
+    const KnnPlan p = *plan;
+    const float qx = new_xyz[(size_t)pt * 3 + 0], qy = new_xyz[(size_t)pt * 3 + 1], qz = new_xyz[(size_t)pt * 3 + 2];
+    const int cx = cell_coord(qx, p.lo[0], p.inv_c, p.dims[0]);
+    const int cy = cell_coord(qy, p.lo[1], p.inv_c, p.dims[1]);
+    const int cz = cell_coord(qz, p.lo[2], p.inv_c, p.dims[2]);
+    const int base = bt * p.ncell;
+    constexpr unsigned long long NONE = ~0ull;
+    const unsigned long long filler = ((unsigned long long)__float_as_uint(1e10f) << 32) | (unsigned)start;  // knnquery_cuda_kernel.cu:88-91
+    unsigned long long cur = filler;   // sorted ascending over the group's lanes
+    unsigned long long worst = filler; // the (k+1)-th best: what a candidate has to beat
+    unsigned long long nk = NONE;      // the batch being filled
+    int fill = 0;                      // (group-uniform)
+    const int gshift = (tid & 63) & ~(LQ - 1);
+    const unsigned long long gmask = LQ == 64 ? ~0ull : (((1ull << LQ) - 1ull) << gshift);
+
+    auto flush = [&]() {
+        if (__ballot(nk < worst) & gmask) {
+            // bitonic sort of the batch, ascending over the group
+#pragma unroll
+            for (int kk = 2; kk <= LQ; kk <<= 1)
+#pragma unroll
+                for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                    const unsigned long long o = group_exchange<LQ>(nk, jj);
+                    const bool up = (sub & kk) == 0, lower = (sub & jj) == 0;
+                    nk = (lower == up) ? (o < nk ? o : nk) : (o > nk ? o : nk);
+                }
+            // the LQ smallest of (cur ascending, batch ascending): minimum with the reversed batch is bitonic; clean it
+            const unsigned long long rv = group_read<LQ>(nk, LQ - 1 - sub);
+            unsigned long long mg = rv < cur ? rv : cur;
+#pragma unroll
+            for (int jj = LQ >> 1; jj > 0; jj >>= 1) {
+                const unsigned long long o = group_exchange<LQ>(mg, jj);
+                mg = ((sub & jj) == 0) ? (o < mg ? o : mg) : (o > mg ? o : mg);
+            }
+            cur = mg;
+            worst = group_read<LQ>(cur, k);
+        }
+        nk = NONE;
+        fill = 0;
+    };
+    auto add_segment = [&](int s, int e) {  // records [s, e) of the cell-ordered candidates
+        while (s < e) {
+            const int n = min(e - s, LQ - fill), rel = sub - fill;
+            if (rel >= 0 && rel < n) {
+                const float4 c = rec[s + rel];
+                const float ddx = qx - c.x, ddy = qy - c.y, ddz = qz - c.z;
+                const float d2 = __fmaf_rn(ddz, ddz, __fmaf_rn(ddx, ddx, __fmul_rn(ddy, ddy)));
+                nk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c.w);
+            }
+            fill += n;
+            s += n;
+            if (fill == LQ) flush();
+        }
+    };
+
+    const int rmax = max(max(p.dims[0], p.dims[1]), p.dims[2]);
+    for (int r = 0; r < rmax; r++) {
+        for (int dz = -r; dz <= r; dz++) {
+            const int z = cz + dz;
+            if (z < 0 || z >= p.dims[2]) continue;
+            for (int dy = -r; dy <= r; dy++) {
+                const int y = cy + dy;
+                if (y < 0 || y >= p.dims[1]) continue;
+                const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+                const int row = base + (z * p.dims[1] + y) * p.dims[0];
+                const int nseg = (face || r == 0) ? 1 : 2;
+                for (int seg = 0; seg < nseg; seg++) {
+                    int x0, x1;
+                    if (face || r == 0) { x0 = max(cx - r, 0); x1 = min(cx + r, p.dims[0] - 1); }
+                    else { x0 = x1 = seg == 0 ? cx - r : cx + r; }
+                    if (x0 < 0 || x1 >= p.dims[0] || x0 > x1) continue;
+                    add_segment(cell_start[row + x0], cell_start[row + x1 + 1]);
+                }
+            }
+        }
+        if (fill > 0) flush();
+        const float wd = __uint_as_float((unsigned)(worst >> 32));
+        // nearest unvisited cell face (sides that have run out of grid do not bound anything)
+        float dmin = INFINITY;
+        bool more = false;
+        if (cx - r > 0) { dmin = fminf(dmin, qx - (p.lo[0] + (cx - r) * p.c)); more = true; }
+        if (cx + r < p.dims[0] - 1) { dmin = fminf(dmin, (p.lo[0] + (cx + r + 1) * p.c) - qx); more = true; }
+        if (cy - r > 0) { dmin = fminf(dmin, qy - (p.lo[1] + (cy - r) * p.c)); more = true; }
+        if (cy + r < p.dims[1] - 1) { dmin = fminf(dmin, (p.lo[1] + (cy + r + 1) * p.c) - qy); more = true; }
+        if (cz - r > 0) { dmin = fminf(dmin, qz - (p.lo[2] + (cz - r) * p.c)); more = true; }
+        if (cz + r < p.dims[2] - 1) { dmin = fminf(dmin, (p.lo[2] + (cz + r + 1) * p.c) - qz); more = true; }
+        if (!more) break;
+        dmin -= 1e-3f * p.c;  // fp32 cell assignment / face arithmetic slack
+        if (dmin > 0.f && wd < dmin * dmin * 0.999f) break;
+    }
+    // exact ties among the k+1 best make the reference's order history-dependent: replay those queries
+    const unsigned long long nxt = group_read<LQ>(cur, min(sub + 1, LQ - 1));
+    const float da = __uint_as_float((unsigned)(cur >> 32)), db = __uint_as_float((unsigned)(nxt >> 32));
+    const bool tie = sub < k && da < 1e10f && da == db;
+    if (__ballot(tie) & gmask) {
+        if (sub == 0) replay[atomicAdd(replay_count, 1)] = pt;
+        return;
+    }
+    if (sub < k) {
+        idx[(size_t)pt * k + sub] = (int)(unsigned)cur;
+        dist2[(size_t)pt * k + sub] = da;
+    }
+}
+
 // literal heap procedure (knn.hip) for the listed queries only
 __global__ __launch_bounds__(64) void knn_replay_kernel(int k, const int *__restrict__ replay, const int *__restrict__ replay_count,
                                                         const float *__restrict__ xyz, const float *__restrict__ new_xyz,
@@ -317,10 +453,21 @@ bool knn_grid_launch(int m, int k, int n, int b, const float *xyz, const float *
     e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, (const unsigned *)qkeys_in, qkeys_out, (const int *)qvals_in, qperm, m, 0,
                                            bits_for_cells(b), st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return true; }
-    constexpr int BS = 64;
-    const size_t lds = (size_t)(k + 1) * BS * 8;
-    hipLaunchKernelGGL(knn_grid_kernel<BS>, dim3(div_up(m, BS)), dim3(BS), lds, st, m, k, new_xyz, offset, new_offset, plan, cell_start, rec,
-                       idx, dist2, replay, replay_count, qperm);
+    static const bool one_lane = getenv("P2_KNN_ONE_LANE") != nullptr;
+    if (k + 1 <= 64 && !one_lane) {  // several lanes per query
+#define P2_KNN_LANES(LQ_)                                                                                                              \
+    hipLaunchKernelGGL(knn_lanes_kernel<LQ_>, dim3((unsigned)div_up64((int64_t)m * LQ_, 256)), dim3(256), 0, st, m, k, new_xyz, offset, new_offset, \
+                       plan, cell_start, rec, idx, dist2, replay, replay_count, qperm)
+        if (k + 1 <= 16) P2_KNN_LANES(16);
+        else if (k + 1 <= 32) P2_KNN_LANES(32);
+        else P2_KNN_LANES(64);
+#undef P2_KNN_LANES
+    } else {
+        constexpr int BS = 64;
+        const size_t lds = (size_t)(k + 1) * BS * 8;
+        hipLaunchKernelGGL(knn_grid_kernel<BS>, dim3(div_up(m, BS)), dim3(BS), lds, st, m, k, new_xyz, offset, new_offset, plan, cell_start, rec,
+                           idx, dist2, replay, replay_count, qperm);
+    }
     hipLaunchKernelGGL(knn_replay_kernel, dim3(min(div_up(m, 64), 1024)), dim3(64), (size_t)k * 64 * 8, st, k, replay, replay_count, xyz, new_xyz,
                        offset, new_offset, idx, dist2);
     return true;

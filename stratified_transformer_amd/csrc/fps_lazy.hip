@@ -407,12 +407,17 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
                 h_top = ld_agent(&h->top); h_tov = ld_agent(&h->tover); h_cnt = ld_agent(&h->count);
             }
             const size_t seg = ((size_t)par * LZ_GMAX + gg) * CAP;
-            float sx = 0.f, sy = 0.f, sz = 0.f, sd = 0.f;
-            unsigned slo = 0u;
-            if (e0 < CAP) {
-                sx = ld_agent(xc4 + (seg + e0) * 4 + 0); sy = ld_agent(xc4 + (seg + e0) * 4 + 1); sz = ld_agent(xc4 + (seg + e0) * 4 + 2);
-                sd = ld_agent(xc4 + (seg + e0) * 4 + 3);
-                slo = ld_agent(xlo + seg + e0);
+            // two entries per thread in flight with the headers: 2 E entries of every list arrive in the first trip
+            float sx[2] = {0.f, 0.f}, sy[2] = {0.f, 0.f}, sz[2] = {0.f, 0.f}, sd[2] = {0.f, 0.f};
+            unsigned slo[2] = {0u, 0u};
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int e = e0 + u * E;
+                if (e < CAP) {
+                    sx[u] = ld_agent(xc4 + (seg + e) * 4 + 0); sy[u] = ld_agent(xc4 + (seg + e) * 4 + 1); sz[u] = ld_agent(xc4 + (seg + e) * 4 + 2);
+                    sd[u] = ld_agent(xc4 + (seg + e) * 4 + 3);
+                    slo[u] = ld_agent(xlo + seg + e);
+                }
             }
             int mybase = 0, mytake = 0, maxtake = 0;
             for (int q = 0; q < G; q++) {  // (uniform)
@@ -427,13 +432,16 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
                 maxtake = max(maxtake, take);
                 K += take;
             }
-            for (int e = e0;; e += E) {
-                if (e < mytake) { cx[mybase + e] = sx; cy[mybase + e] = sy; cz[mybase + e] = sz; cd[mybase + e] = sd; clo[mybase + e] = slo; }
-                if (e - e0 + E >= maxtake) break;  // (uniform) nobody's list is longer than what the passes so far covered
-                if (e + E < mytake) {
-                    sx = ld_agent(xc4 + (seg + e + E) * 4 + 0); sy = ld_agent(xc4 + (seg + e + E) * 4 + 1); sz = ld_agent(xc4 + (seg + e + E) * 4 + 2);
-                    sd = ld_agent(xc4 + (seg + e + E) * 4 + 3);
-                    slo = ld_agent(xlo + seg + e + E);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int e = e0 + u * E;
+                if (e < mytake) { cx[mybase + e] = sx[u]; cy[mybase + e] = sy[u]; cz[mybase + e] = sz[u]; cd[mybase + e] = sd[u]; clo[mybase + e] = slo[u]; }
+            }
+            for (int e = e0 + 2 * E; e - e0 < maxtake; e += E) {  // (uniform trip count) the rare longer list
+                if (e < mytake) {
+                    cx[mybase + e] = ld_agent(xc4 + (seg + e) * 4 + 0); cy[mybase + e] = ld_agent(xc4 + (seg + e) * 4 + 1);
+                    cz[mybase + e] = ld_agent(xc4 + (seg + e) * 4 + 2); cd[mybase + e] = ld_agent(xc4 + (seg + e) * 4 + 3);
+                    clo[mybase + e] = ld_agent(xlo + seg + e);
                 }
             }
         }

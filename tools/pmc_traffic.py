@@ -46,7 +46,7 @@ def launches(prefix):
 # every pass of either kind launches the grid kNN six times
 ops_passes = max(1, launches("a1_fwd_kernel") // blocks_per_pass)
 cell_passes = max(1, launches("cell_fwd_kernel") // blocks_per_pass)
-all_passes = max(1, launches("knn_grid_kernel") // 6)
+all_passes = max(1, (launches("knn_grid_kernel") + launches("knn_lanes_kernel")) // 6)
 steps = all_passes
 per = {"attn_fwd": ops_passes, "attn_bwd": ops_passes, "cell_attn_fwd": cell_passes, "cell_attn_bwd": cell_passes}
 kernels, groups = {}, collections.defaultdict(float)

@@ -469,7 +469,9 @@ __device__ __forceinline__ void flush_key_pass(float *scr, float4 acc, rsrc_t rs
         const int s = (x.lane >> 4) + 4 * kk;
         const int jl = s * NPA + t;
         const int key = (int)bload_u32(rs_key, (j0 + jl) * 4);
+#ifndef CA_SKIP_FLUSH  // (experiment: what the dK / dV atomics cost)
         if (jl < nkc) unsafeAtomicAdd(grad + (size_t)key * x.C + x.head * 16 + (x.lane & 15), scr[s * 16 + (x.lane & 15)]);
+#endif
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();

@@ -36,7 +36,10 @@ constexpr int CA_NP_BWD = 3;  // backward: 48 keys per chunk (key rows AND their
 #define CA_WAVES_OVERRIDE 12
 #endif
 constexpr int CA_WAVES = CA_WAVES_OVERRIDE;  // waves per workgroup (one head's three tables in LDS per workgroup)
-constexpr int CA_WAVES_BWD = 12;             // backward workgroup
+#ifndef CA_WAVES_BWD_OVERRIDE
+#define CA_WAVES_BWD_OVERRIDE 12
+#endif
+constexpr int CA_WAVES_BWD = CA_WAVES_BWD_OVERRIDE;  // backward workgroup
 
 // ---- cross-lane sums without LDS round trips where the hardware has a lane network for it ----
 template <int CTRL>
@@ -853,6 +856,7 @@ static int cell_grid_x(K kernel, size_t lds, int tasks, int h, int waves = CA_WA
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), waves * 64, lds) != hipSuccess || per_cu <= 0)
         per_cu = 1;
+    // (measured: 10 or 8 waves per workgroup are 10-25 % slower, also with two such workgroups forced onto a CU)
     // A few CUs are left to whatever runs beside the blocks (the round sampler holds 16 CUs for milliseconds, kNN and the
     // index build come and go): tasks are dealt by position, so a workgroup that has to WAIT for a CU serves its whole share
     // late and the kernel takes twice as long, while leaving 1/16 of the chip idle costs 1/16.  (A work queue - every further

@@ -178,6 +178,7 @@ def geometry_stream(device, which=0):
     return _GEO_STREAMS[key]
 
 
+EVEN_FIRST = os.environ.get("P2_EVEN_FIRST", "1") != "0"  # the first stage's first block is enqueued from inside its index build
 INDEX_THREAD = os.environ.get("P2_INDEX_THREAD", "0") == "1"  # measured: 16.2 ms against 15.5 ms per pass (the two host threads contend), so opt-in
 
 
@@ -347,7 +348,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
                 clouds[si + 1] = (n_xyz, n_off, n_off_host)
         geo_out[si] = (ds, ev_ds, knn_idx)
 
-    def index(si):
+    def index(si, on_even=None):
         x, off, _ = clouds[si]
         ds, ev_ds, _ = geo_out[si]
         st = cfg.stages[si]
@@ -368,7 +369,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
             if use_hip_index:
                 even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds,
                                          table_rows(st) if (cells or (fused == "cell" and not shard)) else None,
-                                         index_build.cell_query_cap(x.shape[0], st.num_heads), parts_ctx)
+                                         index_build.cell_query_cap(x.shape[0], st.num_heads), parts_ctx, on_even)
             else:
                 parts = timer.run("index/partition", index_build.stage_partitions, x, off, st.window_size)
                 even = timer.run("index/pairs", index_build.build_block_index, x, parts["small"], parts["large"], ds, st.window_size, st.quant_size, False)
@@ -394,8 +395,30 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     # helper thread (own stream; the library's launch state is thread-local), one stage after the other as the geometry
     # arrives, so the launches of the attention blocks never wait behind a later stage's sampling.
     builder = _IndexBuilder(index, stages) if (overlap and INDEX_THREAD) else None
+    started = {}  # si -> output of block 0, when it was enqueued from inside the stage's index build
+
+    def first_block_early(even_blk):
+        """Called by the first stage's index build when the plain pattern exists: its block runs beside the build of the shifted
+        pattern (the pass's start is sampler -> index build -> first block; this takes the second pattern off that path)."""
+        si = first
+        st = cfg.stages[si]
+        x, off, _ = clouds[si]
+        ds = geo_out[si][0]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))  # (the index stream)
+        with torch.cuda.stream(main):
+            main.wait_event(ev)
+            for t in (x, off, ds, even_blk.index_1, even_blk.offsets, even_blk.rel_idx):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+            if make:
+                states.append(make_stage_state(x, off, st, seed + si))
+            state = states[si - first]
+            state.xyz, state.offset = x, off
+            started[si] = attention_block(state, even_blk, timer, False if shard else fused, shard)
+
     if builder is None:
-        index(first)
+        index(first, first_block_early if (overlap and use_hip_index and EVEN_FIRST) else None)
     for si in stages:
         st = cfg.stages[si]
         x, off, _ = clouds[si]
@@ -408,17 +431,19 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
             for t in (x, off, ds, even.index_1, even.offsets, even.rel_idx, odd.index_1, odd.offsets, odd.rel_idx):
                 if torch.is_tensor(t):
                     t.record_stream(main)
-        if make:
+        if make and si not in started:
             states.append(make_stage_state(x, off, st, seed + si))
         state = states[si - first]
         state.xyz, state.offset = x, off
-        out = None
+        out = started.get(si)
         # the next stage's index build stops the host twice; it is issued where the host can afford to wait:
         # behind ALL blocks of the first stage (its samples only arrive when the stage-0 sampler is through),
         # behind the FIRST block of a later stage (its samples are long there, and the late stages' blocks are
         # short enough for the launches to fall behind otherwise)
         early = si + 1 in stages and si > first
         for b in range(st.depth):
+            if b == 0 and si in started:
+                continue
             out = attention_block(state, even if b % 2 == 0 else odd, timer, False if shard else fused, shard)
             if early and b == 0 and builder is None:
                 index(si + 1)

@@ -344,6 +344,20 @@ def test_knn_bit_exact(P):
             assert np.array_equal(d_got, d_ref), (k, offset)
 
 
+def test_knn_lanes_on_a_lattice_full_of_ties(P):
+    """Large enough for the grid path (m * n >= 2^22): every query of an integer lattice has exact distance ties among its k + 1
+    best, so every lane group of knn_lanes_kernel (16 / 32 / 64 lanes per query) hands its query to the literal replay; queries off
+    the lattice (no ties) take the sorted-register path.  Both must equal the oracle bit for bit."""
+    g = np.stack(np.meshgrid(np.arange(24), np.arange(24), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    g = g[np.random.default_rng(5).permutation(len(g))]
+    rng = np.random.default_rng(6)
+    q = np.concatenate([g[:500], (rng.random((500, 3)) * np.array([23, 23, 11])).astype(np.float32)]).astype(np.float32)
+    for k in (3, 16, 40):
+        i_ref, d_ref = ref.knnquery(k, g, q, np.array([len(g)], np.int32), np.array([len(q)], np.int32))
+        i_got, d_got = _knn(P, k, g, q, [len(g)], [len(q)])
+        assert np.array_equal(i_got, i_ref) and np.array_equal(d_got, d_ref), k
+
+
 def test_knn_bit_exact_with_ties_and_short_batches(P):
     g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(6), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
     g = g[np.random.default_rng(4).permutation(len(g))]

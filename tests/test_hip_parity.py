@@ -305,6 +305,18 @@ def test_fps_scene_sizes(P):
     assert np.array_equal(got, ref.furthestsampling(xyz, np.array([20000], np.int32), np.array([2501], np.int32)))
 
 
+def test_fps_ties_and_duplicates_over_several_workgroups(P):
+    """Exact ties everywhere (integer lattice), every point present twice (min-distances reach zero long before the request is
+    served), sampled to exhaustion: large enough for the step-by-step head and four workgroups per cloud - candidate lists
+    overflow, rounds accept nothing and fall back to literal steps, thresholds hit zero.  Bit-exact with the oracle."""
+    g = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(8), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    g = np.concatenate([g, g])[np.random.default_rng(9).permutation(2 * len(g))]
+    n = len(g)  # 16384
+    for m in (n // 8 + 1, n // 2 + 5, n):
+        got = _fps(P, g, [n], [m])
+        assert np.array_equal(got, ref.furthestsampling(g, np.array([n], np.int32), np.array([m], np.int32))), m
+
+
 def test_fps_ragged_batch_over_many_workgroups(P):
     """The round sampler with 16 workgroups per cloud (the largest cloud decides), clouds of very different sizes in one batch
     (workgroups without buckets, a cloud smaller than one bucket, an empty request), more batch elements than one launch holds

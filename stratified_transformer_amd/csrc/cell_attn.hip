@@ -24,12 +24,16 @@
 // Cells with more than 16 * CA_NP keys are taken in chunks (a running max / sum per query in `ml`, logits parked
 // in pbuf); the shipped configs never need more than one chunk.
 #include "rpe_common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace p2 {
 
 typedef float __attribute__((ext_vector_type(4))) f32x4c;
 
+#ifdef CA_TRACE
+__device__ unsigned long long ca_trace[3 * 1024];
+#endif
 constexpr int CA_NP = 8;      // forward: passes of 16 keys a lane keeps in registers (128 keys per chunk)
 constexpr int CA_NP_BWD = 3;  // backward: 48 keys per chunk (key rows AND their gradient accumulators in registers; chunks simply add up)
 #ifndef CA_WAVES_OVERRIDE
@@ -427,6 +431,9 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_
     __syncthreads();
     const int nC = pl.counts[0];
     float *pb = pbuf + (size_t)x.head * plane;
+#ifdef CA_TRACE  // diagnostic build (tools/interference.py): when and where every workgroup of the forward kernel ran
+    const unsigned long long tr_t0 = wall_clock64();
+#endif
     const int slots = gridDim.x * CA_WAVES, slot = blockIdx.x * CA_WAVES + wave;
     for (int round = 0; round * slots < nC; round++) {
         const int task = snake_task(round, slot, slots);
@@ -454,6 +461,17 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_
         }
 #endif
     }
+#ifdef CA_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (wg < 1024) {
+            ca_trace[wg * 3 + 0] = tr_t0;
+            ca_trace[wg * 3 + 1] = wall_clock64();
+            ca_trace[wg * 3 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // HW_ID, XCC_ID
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -849,21 +867,27 @@ __global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops
 }
 
 static int device_cus() { return num_cus(); }
-// persistent grid of the cell walkers: exactly the workgroups the chip holds at once (tasks are dealt to resident waves;
-// a workgroup that had to wait for a CU would start its share late), over all heads; never more waves than tasks
-template <typename K>
-static int cell_grid_x(K kernel, size_t lds, int tasks, int h, int waves = CA_WAVES) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), waves * 64, lds) != hipSuccess || per_cu <= 0)
-        per_cu = 1;
-    // (measured: 10 or 8 waves per workgroup are 10-25 % slower, also with two such workgroups forced onto a CU)
-    // A few CUs are left to whatever runs beside the blocks (the round sampler holds 16 CUs for milliseconds, kNN and the
-    // index build come and go): tasks are dealt by position, so a workgroup that has to WAIT for a CU serves its whole share
-    // late and the kernel takes twice as long, while leaving 1/16 of the chip idle costs 1/16.  (A work queue - every further
-    // task from a device-scope counter - was measured: the contended atomics cost more than the imbalance.)
-    static const int reserve = getenv("P2_CELL_RESERVE_CUS") ? atoi(getenv("P2_CELL_RESERVE_CUS")) : 0;  // (measured 0 / 16 / 32 / 48: no difference beyond noise, so nothing is reserved)
-    const int cus = max(device_cus() - max(reserve, 0), device_cus() / 2);
-    const int cap = max(1, per_cu * cus / max(h, 1));
+#ifdef CA_TRACE
+} // namespace p2
+extern "C" void pointops2_diag_read_cell_trace(unsigned long long *host) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(p2::ca_trace), sizeof(unsigned long long) * 3 * 1024); }
+namespace p2 {
+#endif
+// Persistent grid of the cell walkers: `per_cu` workgroups for every CU that is FREE, over all heads; never more waves than
+// tasks.  Tasks are dealt by position, so a workgroup that has to wait for a CU serves its whole share late and the kernel
+// takes twice as long (tools/cell_trace.py: 16 CUs held -> 31 of 255 workgroups start when the others finish).  The one
+// long-running kernel of this library is the round sampler (16 workgroups per cloud for milliseconds): its launches are noted
+// (common.h, held_cus_*), and while any of them has not finished the grid leaves its shader engines room: workgroups go to
+// the 32 shader engines (8 CUs each) in turn, so one CU less per engine for every 32 held workgroups.  Measured, stage-0
+// forward: 265 us alone, 451 us beside 16 held CUs, 314 us with a grid of 7 per engine (283 us alone with that grid).
+// (Other designs measured: a work queue - contended device-scope atomics, 1.2x slower alone; several workgroups per CU taking
+// contiguous task ranges in dispatch order - the table staging per workgroup and idle waves cost 1.1-1.4x alone; fewer waves
+// per workgroup with more workgroups per CU - 1.1-1.5x slower.)
+static int cell_grid_x(int per_cu, int tasks, int h, int waves) {
+    const int cus = device_cus(), engines = max(cus / 8, 1);
+    const int held = held_cus_now();
+    const int per_engine = held > 0 ? max(8 - (held + 31) / 32, 2) : 8;
+    const int avail = min(cus, engines * per_engine);
+    const int cap = max(1, per_cu * avail / max(h, 1));
     return max(1, min(cap, div_up(tasks, waves)));
 }
 
@@ -878,13 +902,13 @@ static void launch_cell_fwd(const pointops2_cell_plan *plan, int h, int hdim, in
     if (L <= 80) {
         const size_t lds = TabGeo<80>::bytes(sizeof(T));
         allow_big_lds(cell_fwd_kernel<CA_NP, 80, T>, lds);
-        const dim3 grid(cell_grid_x(cell_fwd_kernel<CA_NP, 80, T>, lds, plan->n_cells, h), h);
+        const dim3 grid(cell_grid_x(1, plan->n_cells, h, CA_WAVES), h);
         hipLaunchKernelGGL((cell_fwd_kernel<CA_NP, 80, T>), grid, block, lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out, ml,
                            pbuf, plane);
     } else if (L <= 160) {
         const size_t lds = TabGeo<160>::bytes(sizeof(T));
         allow_big_lds(cell_fwd_kernel<CA_NP, 160, T>, lds);
-        const dim3 grid(cell_grid_x(cell_fwd_kernel<CA_NP, 160, T>, lds, plan->n_cells, h), h);
+        const dim3 grid(cell_grid_x(1, plan->n_cells, h, CA_WAVES), h);
         hipLaunchKernelGGL((cell_fwd_kernel<CA_NP, 160, T>), grid, block, lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out, ml,
                            pbuf, plane);
     } else {
@@ -905,11 +929,11 @@ static void launch_cell_bwd(const pointops2_cell_plan *plan, int h, int hdim, in
     const size_t lds = TabGeo<80>::bytes(sizeof(T)) + (size_t)CA_WAVES_BWD * 256 * sizeof(float);
     allow_big_lds(cell_bwd_kernel<CA_NP_BWD, 80, T>, lds);
     const size_t plane = (size_t)plan->n_pairs;
-    hipLaunchKernelGGL((cell_bwd_kernel<CA_NP_BWD, 80, T>), dim3(cell_grid_x(cell_bwd_kernel<CA_NP_BWD, 80, T>, lds, plan->n_cells, h, CA_WAVES_BWD), h),
+    hipLaunchKernelGGL((cell_bwd_kernel<CA_NP_BWD, 80, T>), dim3(cell_grid_x(1, plan->n_cells, h, CA_WAVES_BWD), h),
                        dim3(CA_WAVES_BWD * 64), lds, st, *plan, h, L, grad_out, q, k, v, out, table_q, table_k, table_v, pbuf, gsbuf, plane, grad_q,
                        grad_k, grad_v);
     // the three table gradients read p / gs only
-    const int gx_t = max(1, min(2 * device_cus() / max(h, 1), div_up(plan->n_cells, CT_WAVES)));
+    const int gx_t = cell_grid_x(2, plan->n_cells, h, CT_WAVES);
     const dim3 tgrid(gx_t, h), tblock(CT_WAVES * 64);
     if (L <= 64) {
         using G = CellTableGeo<4>;

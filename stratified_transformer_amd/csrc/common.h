@@ -82,6 +82,11 @@ class ForkJoin {
     bool enabled_;
 };
 
+// Long-running kernels of this library that hold CUs (the round sampler: 16 workgroups per cloud for milliseconds) note their
+// launch here; the persistent-grid kernels ask how many such workgroups may still be running (an event per launch, polled).
+void held_cus_note(hipStream_t st, int workgroups);
+int held_cus_now();
+
 constexpr int WAVE = 64;
 constexpr int kNumCU = 256;  // MI355X (fallback when the device cannot be queried)
 // compute units of the current device, queried once (a partitioned device has fewer); sizes the persistent grids

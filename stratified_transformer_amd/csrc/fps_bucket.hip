@@ -773,6 +773,7 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
         if (pidx == nullptr && head > 0 && n >= 8192) {
             hipLaunchKernelGGL(fps_head_offsets_kernel, dim3(1), dim3(64), 0, st, b, head, new_offset, head_offset);
             P2_FPS_STEPWISE(head_offset, (const int *)nullptr, (const int *)nullptr, head_idx);
+            held_cus_note(st, b);  // (one workgroup per cloud holds a CU for the head's ~1 ms)
             pidx = head_idx;
             poff = head_offset;
         }
@@ -801,6 +802,7 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
         return true;
     }
     P2_FPS_STEPWISE(new_offset, rs.prev_idx, rs.prev_offset, idx);
+    held_cus_note(st, b);
 #undef P2_FPS_STEPWISE
 #undef P2_FPS_LAUNCH
     return true;

@@ -64,24 +64,29 @@ template <typename T>
 __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // All G workgroups of a batch element arrive; every workgroup reaches it the same number of times (the control flow around
-// it is replicated), so the grid always drains.  Cross-workgroup data is written and read with device-scope accesses; the
-// workgroup barriers order the other threads' accesses around thread 0's release / acquire.
+// it is replicated), so the grid always drains.  EVERY byte that crosses workgroups is written by a device-scope (sc1) store
+// and read by a device-scope (sc1) load, every storing wave drains its stores (vmcnt(0)) before the workgroup's barrier, and
+// the counter itself is a relaxed device-scope atomic: no release / acquire FENCE anywhere.  A fence would write back and
+// invalidate the whole L2 of the workgroup's XCD - sixteen workgroups on eight XCDs, every ~35 us - and the attention kernels
+// that run beside the sampler live on L2 hits: with release / acquire atomics here they took 1.6x (forward) to 2x (backward)
+// as long (tools/interference.py).
 // Safety net: a workgroup that has waited LZ_PATIENCE ticks of the 100 MHz clock (2 s: the whole kernel takes milliseconds)
 // poisons the counter, which releases every waiter of the element, and all of them leave (returns false): a grid that cannot
 // make progress for a reason outside the algorithm must still drain.
 constexpr unsigned LZ_POISON = 0x40000000u;
 constexpr unsigned long long LZ_PATIENCE = 200000000ull;
 __device__ __forceinline__ bool group_barrier(unsigned *bar, unsigned target, int G, int *s_flag) {
-    __syncthreads();  // (workgroup-scope release: every wave's stores have left the CU)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's device-scope stores have been performed
+    __syncthreads();
     if (threadIdx.x == 0) {
         unsigned v = target;
         if (G > 1) {
-            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = wall_clock64();
-            while ((v = __hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+            while ((v = __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
                 __builtin_amdgcn_s_sleep(1);
                 if (wall_clock64() - t0 > LZ_PATIENCE) {
-                    __hip_atomic_fetch_add(bar, LZ_POISON, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(bar, LZ_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     v = LZ_POISON;
                     break;
                 }
@@ -729,6 +734,7 @@ void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, co
             hipLaunchKernelGGL((fps_lazy_kernel<false, LZ_NSLOT>), grid, dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, c0, xyz, offset, new_offset, pts, rank, prev_idx,
                                prev_offset, verified, idx, (unsigned char *)xchg, (unsigned long long *)nullptr);
         }
+        held_cus_note(st, (int)(grid.x * grid.y));
     }
 }
 

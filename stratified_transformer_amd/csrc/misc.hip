@@ -1,5 +1,6 @@
 // Launch state, row gathers (grouping / interpolation) and the CSR <-> key-major (CSC) transposition.
 #include "common.h"
+#include <mutex>
 #include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
@@ -138,6 +139,55 @@ static size_t cub_sort_bytes(int N, int M) {
 
 using namespace p2;
 
+namespace p2 {
+namespace {
+struct HeldSlot { hipEvent_t ev = nullptr; int wgs = 0; bool live = false; };
+HeldSlot held_slots[16];
+int held_next = 0;
+std::mutex held_mutex;
+}  // namespace
+void held_cus_note(hipStream_t st, int workgroups) {
+    std::lock_guard<std::mutex> g(held_mutex);
+    HeldSlot &s = held_slots[held_next];
+    held_next = (held_next + 1) % 16;
+    if (s.ev == nullptr && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return; }
+    if (hipEventRecord(s.ev, st) != hipSuccess) { s.live = false; return; }
+    s.wgs = workgroups;
+    s.live = true;
+}
+int held_cus_now() {
+    static const bool off = getenv("P2_NO_HELD_CUS") != nullptr;
+    if (off) return 0;
+    std::lock_guard<std::mutex> g(held_mutex);
+    int total = 0;
+    for (HeldSlot &s : held_slots) {
+        if (!s.live) continue;
+        if (hipEventQuery(s.ev) == hipErrorNotReady) total += s.wgs;
+        else s.live = false;
+    }
+    return total;
+}
+}  // namespace p2
+
+namespace p2 {
+__global__ __launch_bounds__(1024) void diag_hold_kernel(int micros, int mode, unsigned *word) {
+    extern __shared__ unsigned char diag_lds[];
+    const unsigned long long t0 = wall_clock64(), ticks = (unsigned long long)micros * 100ull;  // 100 MHz
+    unsigned acc = 0;
+    while (wall_clock64() - t0 < ticks) {
+        if (mode >= 1 && threadIdx.x == 0) acc += __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mode >= 2) {
+            __hip_atomic_store(word + 64 + blockIdx.x * 1024 + threadIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc += __hip_atomic_load(word + 64 + ((blockIdx.x + 1) % gridDim.x) * 1024 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 300; i++) __builtin_amdgcn_s_sleep(1);
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (acc == 0xdeadbeefu) diag_lds[threadIdx.x] = 1;  // (keeps acc and the LDS allocation alive)
+}
+}  // namespace p2
+
 extern "C" {
 
 void pointops2_set_stream(void *hip_stream) { state().stream = reinterpret_cast<hipStream_t>(hip_stream); }
@@ -215,6 +265,14 @@ void pointops2_csc_build(int N, int M, const int *index0_offsets, const int *ind
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
     hipLaunchKernelGGL(csc_finish_kernel, dim3(div_up(M, 256)), dim3(256), 0, st, NK, M, keys, csc_pair, index0, csc_offsets, csc_query);
     check_launch();
+}
+
+// Diagnostic only (tools/interference.py; not part of the header): `blocks` workgroups of 1024 threads with 128 VGPRs' worth of
+// occupancy hold their CUs for `micros` microseconds; mode 0 spins in registers, 1 polls `word` with device-scope atomic loads,
+// 2 also stores to / loads from `word + 64...` with device-scope accesses every ~10 us.
+void pointops2_diag_hold_cus_launcher(int blocks, int micros, int mode, unsigned *word, int lds_kb) {
+    allow_big_lds(diag_hold_kernel, (size_t)lds_kb * 1024);  // (120 KB: no cell workgroup fits beside it)
+    hipLaunchKernelGGL(diag_hold_kernel, dim3(blocks), dim3(1024), (size_t)lds_kb * 1024, state().stream, micros, mode, word);
 }
 
 }  // extern "C"

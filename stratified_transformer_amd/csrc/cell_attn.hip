@@ -883,11 +883,7 @@ namespace p2 {
 // contiguous task ranges in dispatch order - the table staging per workgroup and idle waves cost 1.1-1.4x alone; fewer waves
 // per workgroup with more workgroups per CU - 1.1-1.5x slower.)
 static int cell_grid_x(int per_cu, int tasks, int h, int waves) {
-    const int cus = device_cus(), engines = max(cus / 8, 1);
-    const int held = held_cus_now();
-    const int per_engine = held > 0 ? max(8 - (held + 31) / 32, 2) : 8;
-    const int avail = min(cus, engines * per_engine);
-    const int cap = max(1, per_cu * avail / max(h, 1));
+    const int cap = max(1, per_cu * usable_cus() / max(h, 1));
     return max(1, min(cap, div_up(tasks, waves)));
 }
 

@@ -99,6 +99,17 @@ inline int num_cus() {
     return cus;
 }
 
+// CUs a persistent grid should count on right now: workgroups are handed to the shader engines (8 CUs each) in turn, and one
+// that has to wait for a CU held by a long-running kernel serves its whole static share late (cell_attn.hip, cell_grid_x): one
+// CU less per engine for every 32 workgroups of noted launches that have not finished.
+inline int usable_cus() {
+    const int cus = num_cus(), engines = cus / 8 > 0 ? cus / 8 : 1;
+    const int held = held_cus_now();
+    if (held <= 0) return cus;
+    const int per_engine = 8 - (held + 31) / 32 > 2 ? 8 - (held + 31) / 32 : 2;
+    return engines * per_engine < cus ? engines * per_engine : cus;
+}
+
 // Dynamic LDS above the 64 KiB default needs an explicit opt-in per kernel (gfx950: 160 KiB per CU).
 template <typename K>
 inline void allow_big_lds(K kernel, size_t bytes) {

@@ -556,8 +556,9 @@ static int table_rows_or_error() {
 // waves_per_block: rows a workgroup handles at a time; per_cu: resident workgroups per CU (LDS / register budget)
 static int persistent_blocks(int rows, int head_groups, int waves_per_block = 4, int per_cu = 2) {
     int want = div_up(rows, waves_per_block);
-    int cap = num_cus() * per_cu;
-    if (head_groups > 1) cap = max(num_cus() * per_cu / head_groups, num_cus() / 2);
+    const int cus = usable_cus();
+    int cap = cus * per_cu;
+    if (head_groups > 1) cap = max(cus * per_cu / head_groups, cus / 2);
     return min(want, cap);
 }
 

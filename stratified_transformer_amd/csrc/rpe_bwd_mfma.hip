@@ -580,8 +580,9 @@ __global__ __launch_bounds__(512, 4) void wattn_bwd_key_kernel(int NK, int h, in
 // ---- launchers -------------------------------------------------------------------------------------------
 static int walk_blocks(int rows, int groups, int waves_per_block, int per_cu) {
     int want = div_up(rows, waves_per_block);
-    int cap = num_cus() * per_cu;
-    if (groups > 1) cap = max(num_cus() * per_cu / groups, num_cus() / 2);
+    const int cus = usable_cus();
+    int cap = cus * per_cu;
+    if (groups > 1) cap = max(cus * per_cu / groups, cus / 2);
     return max(1, min(want, cap));
 }
 

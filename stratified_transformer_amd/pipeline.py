@@ -486,15 +486,24 @@ def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused
     pace_lag = int(os.environ.get("P2_PACE_LAG", "1"))  # released on batch k-lag: 22.2 / 24.0 / 28.8 ms per step for 1 / 2 / 3
     ahead = len(lanes) - 1  # geometry phases queued in front of the attention phase being enqueued
     queue = [start(k) for k in range(min(ahead, steps))]
-    for k in range(steps):
+    blocks_first = os.environ.get("P2_BLOCKS_FIRST", "1") != "0" and ahead > 0
+
+    def release_geometry(k):
         if k + ahead < steps:
             # Pacing: the geometry of batch k+ahead is released when batch k-1 is through, so a fixed number of
             # sampling chains is in flight, evenly spaced.  Released as early as the host can (three chains start
             # in a burst, slow each other and the attention kernels beside them) a step takes 28.5 instead of 24.8 ms;
             # with the same dependency on the device only (side streams waiting for the lane's main stream) 26.9 ms.
-            if paced and len(done_events) >= pace_lag:
-                done_events[-pace_lag].synchronize()
+            if paced and len(done_events) >= pace_lag + (1 if blocks_first else 0):
+                done_events[-pace_lag - (1 if blocks_first else 0)].synchronize()
             queue.append(start(k + ahead))
+
+    for k in range(steps):
+        # Round 2: the index builds and blocks of batch k are enqueued BEFORE the host waits for batch k-1 (the pacing of the
+        # geometry): with the sampler at 5 instead of 27 ms the wait, the geometry launches and the first index build of batch k
+        # otherwise leave the attention stream idle for 2-3 ms per batch (P2_BLOCKS_FIRST=0: the round-1 order).
+        if not blocks_first:
+            release_geometry(k)
         gen = queue.pop(0)
         with torch.cuda.stream(lanes[k % len(lanes)][0]):
             try:
@@ -507,4 +516,6 @@ def passes_in_flight(xyz_list, offset_list, cfg, lanes, steps, timer=None, fused
             prev_done = torch.cuda.Event()
             prev_done.record(torch.cuda.current_stream())
             done_events.append(prev_done)
+        if blocks_first:
+            release_geometry(k)
     return last

@@ -117,7 +117,7 @@ def run_gpu(args, rank, world):
 
     out = dict(cfg=cfg, xyz_np=xyz_np, dev=dev, xyz=xyz, offset=offset)
     # resident synthetic tensors (q/k/v/tables/grad_out stand in for the Linear layers); created once, not timed
-    states, results = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + (0 if shard else rank), fused=False if shard else "cell", shard=shard)
+    states, results = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + (0 if shard else rank), fused="cell", shard=shard)
 
     def single_pass_leg(fused):
         nonlocal states
@@ -135,14 +135,15 @@ def run_gpu(args, rank, world):
         return dict(elapsed=elapsed, live=live, results=res)
 
     out["single_ops"] = single_pass_leg(False)
-    # (the sharded scene runs the operator path: sharding.py cuts the CSR pair list by query range; a cell plan per query range is next)
-    out["single_cell"] = out["single_ops"] if shard else single_pass_leg("cell")
+    # (sharded scene: operator_api = queries cut by range, all-gather k / v; cell = every world-th cell of the size-sorted list per
+    #  rank, all-gather q / k / v, reduce-scatter of the output - sharding.py)
+    out["single_cell"] = single_pass_leg("cell")
     out["results"], out["states"] = out["single_ops"]["results"], states
 
     # every component, from passes run again with events around every op (not the timed region)
     timer = pipeline.Timer(True)
     for _ in range(args.steps):
-        pipeline.scene_pass(xyz, offset, cfg, states, timer, fused=False if shard else "cell", shard=shard)
+        pipeline.scene_pass(xyz, offset, cfg, states, timer, fused="cell", shard=shard)
     barrier()
     out["timer"] = timer
 
@@ -381,9 +382,10 @@ def main():
             "config": {"workload": "one synthetic S3DIS-like room of 100000 points %s (BASELINE config 3, fp32: fwd+bwd), "
                                    "s3dis_stratified_transformer.yaml stages w=[.16,.32,.64,1.28] C=[48,96,192,384] h=[3,6,12,24] depths=[2,2,6,2]; "
                                    "unit = index build + FPS + depth x attention block fwd+bwd + TransitionDown FPS/kNN16 + Upsample kNN3 per stage; "
-                                   "value = single_pass.%s" % ("sharded over the ranks" if sharded else "per GPU", "operator_api (sharded)" if sharded else "cell"),
+                                   "value = single_pass.%s" % ("sharded over the ranks" if sharded else "per GPU", "cell (sharded)" if sharded else "cell"),
                        "points_per_scene": N_POINTS, "stages": step_attention_bytes(run["cfg"], run["results"])[1],
-                       "parallelism": ("1 scene over %d ranks: queries sharded by pair count, all-gather k/v, reduce-scatter dk/dv, all-reduce table grads" % world)
+                       "parallelism": ("1 scene over %d ranks: cells dealt to the ranks by size order, all-gather q/k/v, reduce-scatter out and dq/dk/dv, all-reduce table grads "
+                                       "(operator_api: queries sharded by pair count, all-gather k/v, reduce-scatter dk/dv)" % world)
                        if sharded else "1 scene per rank, no data-path collective"},
             "single_pass": {"cell": cell, "operator_api": ops,
                             "note": "K passes, each complete before the next starts; cell: attention blocks through fused.cell_attention "

@@ -278,6 +278,10 @@ typedef struct pointops2_cell_plan {
     const int *cell_keys;    /* [K]   key (point) ids per cell: dense keys ascending, then stratified candidates ascending */
     const int *kcell;        /* [K]   cell of a key slot */
     const unsigned int *relp;/* [P]   packed rel-pos index + "not a key" flag */
+    int task_first;          /* the launch works on the cells cell_perm[task_first + i * task_step] only (one scene over several */
+    int task_step;           /* ranks: rank r of w takes r, r + w, ... - cells are sorted by size, so the shares are balanced); */
+                             /* 0 / 0 (or step 1): all cells.  A partial forward writes only its cells' rows of `out`, a partial */
+                             /* backward only its queries' rows of grad_q: zero-fill them and sum over the ranks. */
 } pointops2_cell_plan;
 size_t pointops2_cell_plan_workspace_bytes(int N);
 void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_cluster, const int *s_starts, const int *l_cluster,

@@ -240,6 +240,15 @@ __device__ __forceinline__ CellTask cell_task(const pointops2_cell_plan &pl, int
 // Tasks are sorted by decreasing tile size and dealt to the resident waves in boustrophedon order (round r forwards,
 // round r+1 backwards), so that no wave collects the largest task of every round.
 __device__ __forceinline__ int snake_task(int round, int slot, int slots) { return round * slots + ((round & 1) ? slots - 1 - slot : slot); }
+// A launch may work on a share of the cells only (pointops2_cell_plan.task_first / task_step: one scene over several ranks):
+// the i-th task of the launch is cell_perm[first + i * step]
+__device__ __forceinline__ int share_count(const pointops2_cell_plan &pl, int n) {
+    const int step = pl.task_step > 1 ? pl.task_step : 1, first = pl.task_step > 1 ? pl.task_first : 0;
+    return n > first ? (n - first + step - 1) / step : 0;
+}
+__device__ __forceinline__ int share_task(const pointops2_cell_plan &pl, int i) {
+    return pl.task_step > 1 ? pl.task_first + i * pl.task_step : i;
+}
 
 // A chunk of a cell has np = 1..NP passes of 16 keys (wave-uniform).  The sweeps are straight-line code for a fixed
 // number of passes - the table rows of pass t+1 are requested before pass t is consumed, which a per-pass branch
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_
     stage_table_t<T>(lds + TS, table_k, L, h, x.head);
     stage_table_t<T>(lds + 2 * TS, table_v, L, h, x.head);
     __syncthreads();
-    const int nC = pl.counts[0];
+    const int nC = share_count(pl, pl.counts[0]);
     float *pb = pbuf + (size_t)x.head * plane;
 #ifdef CA_TRACE  // diagnostic build (tools/interference.py): when and where every workgroup of the forward kernel ran
     const unsigned long long tr_t0 = wall_clock64();
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(CA_WAVES * 64) void cell_fwd_kernel(pointops2_cell_
     for (int round = 0; round * slots < nC; round++) {
         const int task = snake_task(round, slot, slots);
         if (task >= nC) continue;
-        const CellTask ct = cell_task(pl, task);
+        const CellTask ct = cell_task(pl, share_task(pl, task));
         const int nch = (ct.nk + 16 * NP - 1) / (16 * NP);
         const unsigned tile_bytes = (unsigned)ct.nq * ct.nk * 4u;
         CellBufs cb;
@@ -639,14 +648,14 @@ __global__ __launch_bounds__(CA_WAVES_BWD * 64) void cell_bwd_kernel(pointops2_c
     stage_table_t<T>(lds + TS, table_k, L, h, x.head);
     stage_table_t<T>(lds + 2 * TS, table_v, L, h, x.head);
     __syncthreads();
-    const int nC = pl.counts[0];
+    const int nC = share_count(pl, pl.counts[0]);
     const float *pb = pbuf + (size_t)x.head * plane;
     float *gb = gsbuf + (size_t)x.head * plane;
     const int slots = gridDim.x * CA_WAVES_BWD, slot = blockIdx.x * CA_WAVES_BWD + wave;
     for (int round = 0; round * slots < nC; round++) {
         const int task = snake_task(round, slot, slots);
         if (task >= nC) continue;
-        const CellTask ct = cell_task(pl, task);
+        const CellTask ct = cell_task(pl, share_task(pl, task));
         const int nch = (ct.nk + 16 * NP - 1) / (16 * NP);
         const unsigned tile_bytes = (unsigned)ct.nq * ct.nk * 4u;
         CellBufs cb;
@@ -736,7 +745,9 @@ __global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops
 
     // rows = queries: a task is a cell (piece), largest first; rows = keys: a task is a parent (all pieces of an uncut cell:
     // one [sum n_q, n_k] tile), so that a key's column is as long as the cut allows
-    const int nC = BYKEY ? pl.counts[4] : pl.counts[0];
+    // (a share of the cells - one scene over several ranks - applies to the query side; the key side walks every parent, and the
+    //  caller zero-fills the weight planes so that the pieces of other ranks contribute nothing)
+    const int nC = BYKEY ? pl.counts[4] : share_count(pl, pl.counts[0]);
     const int slots = gridDim.x * CT_WAVES, slot = blockIdx.x * CT_WAVES + wave;
     for (int round = 0; round * slots < nC; round++) {
         const int task = snake_task(round, slot, slots);
@@ -750,7 +761,7 @@ __global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops
             ct.nk = __builtin_amdgcn_readfirstlane(pl.cell_kbase[c0 + 1]) - ct.kb;
             ct.pbase = __builtin_amdgcn_readfirstlane(pl.cell_pbase[c0]);
         } else {
-            ct = cell_task(pl, task);
+            ct = cell_task(pl, share_task(pl, task));
         }
         const unsigned tile_bytes = (unsigned)ct.nq * ct.nk * 4u;
         const rsrc_t rs_rel = make_rsrc(pl.relp + ct.pbase, tile_bytes);

@@ -117,9 +117,12 @@ class CellAttention(Function):
         pointops_cuda._chk((q, st, "q"), (k, st, "k"), (v, st, "v"), (table_q, st, "table_q"), (table_k, st, "table_k"), (table_v, st, "table_v"))
         assert table_k.shape == table_q.shape and table_v.shape == table_q.shape
         dev = q.device
-        out = torch.empty((N, h, hdim), dtype=torch.float32, device=dev)
+        # a plan restricted to a share of the cells (CellPlan.share: one scene over several ranks) leaves the other cells' rows and
+        # tile entries untouched: they must read as zero (the ranks' outputs are summed; the key-side table gradient walks all cells)
+        alloc = torch.zeros if plan.partial else torch.empty
+        out = alloc((N, h, hdim), dtype=torch.float32, device=dev)
         ml = torch.empty((N, h, 2), dtype=torch.float32, device=dev)
-        pbuf = torch.empty((h, max(plan.n_pairs, 1)), dtype=torch.float32, device=dev)
+        pbuf = alloc((h, max(plan.n_pairs, 1)), dtype=torch.float32, device=dev)
         _lib.call("cell_attention_forward_launcher" if st == torch.float32 else "cell_attention_forward_bf16_launcher", plan.c_arg(), h, hdim, L, ptr(q), ptr(k), ptr(v), ptr(table_q), ptr(table_k), ptr(table_v),
                   ptr(out), ptr(ml), ptr(pbuf), device=dev)
         ctx.plan = plan
@@ -135,9 +138,9 @@ class CellAttention(Function):
         dev = q.device
         grad_out = grad_out.contiguous()
         pointops_cuda._chk((grad_out, torch.float32, "grad_out"))
-        gsbuf = torch.empty_like(pbuf)
+        gsbuf = torch.zeros_like(pbuf) if plan.partial else torch.empty_like(pbuf)
         f32 = dict(dtype=torch.float32, device=dev)
-        grad_q = torch.empty(q.shape, **f32)
+        grad_q = (torch.zeros if plan.partial else torch.empty)(q.shape, **f32)
         # the five accumulated gradients are views of ONE zero-filled buffer: one fill kernel instead of five per block
         nkv, ntab = k.numel(), table_q.numel()
         acc = torch.zeros(2 * nkv + 3 * ntab, **f32)

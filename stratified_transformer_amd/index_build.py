@@ -193,7 +193,8 @@ class CellPlanStruct(ctypes.Structure):
     _fields_ = [("n_points", ctypes.c_int), ("n_cells", ctypes.c_int), ("n_parents", ctypes.c_int), ("n_pairs", ctypes.c_int),
                 ("n_keyslots", ctypes.c_int), ("counts", ctypes.c_void_p), ("parent_first", ctypes.c_void_p), ("cell_perm", ctypes.c_void_p), ("cell_qstart", ctypes.c_void_p),
                 ("cell_kbase", ctypes.c_void_p), ("cell_pbase", ctypes.c_void_p), ("cell_order", ctypes.c_void_p),
-                ("qcell", ctypes.c_void_p), ("cell_keys", ctypes.c_void_p), ("kcell", ctypes.c_void_p), ("relp", ctypes.c_void_p)]
+                ("qcell", ctypes.c_void_p), ("cell_keys", ctypes.c_void_p), ("kcell", ctypes.c_void_p), ("relp", ctypes.c_void_p),
+                ("task_first", ctypes.c_int), ("task_step", ctypes.c_int)]
 
 
 @dataclass
@@ -220,6 +221,8 @@ class CellPlan:
     kcell: torch.Tensor            # [K] i32
     relp: torch.Tensor             # [P] i32 (bit pattern of the packed word)
     struct: CellPlanStruct = None
+    task_first: int = 0            # this launch's share of the cells: cell_perm[task_first::task_step] (share(): one scene over ranks)
+    task_step: int = 1
 
     def c_arg(self):
         from ._lib import ptr
@@ -227,8 +230,17 @@ class CellPlan:
             self.struct = CellPlanStruct(self.n_points, self.n_cells, self.n_parents, self.n_pairs, self.n_keyslots, ptr(self.counts),
                                          ptr(self.parent_first), ptr(self.cell_perm), ptr(self.cell_qstart),
                                          ptr(self.cell_kbase), ptr(self.cell_pbase), ptr(self.cell_order), ptr(self.qcell), ptr(self.cell_keys),
-                                         ptr(self.kcell), ptr(self.relp))
+                                         ptr(self.kcell), ptr(self.relp), int(self.task_first), int(self.task_step))
         return ctypes.byref(self.struct)
+
+    @property
+    def partial(self):
+        return self.task_step > 1
+
+    def share(self, rank, world):
+        """The same plan restricted to every world-th cell (by size order) starting at `rank`: the unit of sharding.sharded_cell_attention."""
+        import dataclasses
+        return dataclasses.replace(self, struct=None, task_first=int(rank), task_step=int(world))
 
     def tensors(self):
         return (self.counts, self.parent_first, self.cell_perm, self.cell_desc, self.cell_qstart, self.cell_kbase, self.cell_pbase, self.cell_order, self.qcell,

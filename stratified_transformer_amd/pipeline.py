@@ -133,8 +133,13 @@ def attention_block(state, blk, timer, fused=False, shard=None):
         sh, bounds, _ = blk.shard
         sharding.set_timer(timer)
         try:
-            out = timer.run("attn_fwd/sharded", sharding.sharded_window_attention, P, sh, bounds, rank, q[sh.lo:sh.hi], k[sh.lo:sh.hi], v[sh.lo:sh.hi],
-                            tq, tk, tv, blk.n_max)
+            if fused == "cell":  # the window-centric kernels on this rank's share of the cells (same row bounds)
+                from . import fused as F
+                out = timer.run("attn_fwd/sharded_cell", sharding.sharded_cell_attention, F.cell_attention, blk.cells, bounds, rank,
+                                q[sh.lo:sh.hi], k[sh.lo:sh.hi], v[sh.lo:sh.hi], tq, tk, tv)
+            else:
+                out = timer.run("attn_fwd/sharded", sharding.sharded_window_attention, P, sh, bounds, rank, q[sh.lo:sh.hi], k[sh.lo:sh.hi], v[sh.lo:sh.hi],
+                                tq, tk, tv, blk.n_max)
             timer.run("attn_bwd", out.backward, state.grad_out[sh.lo:sh.hi])
         finally:
             sharding.set_timer(None)
@@ -368,7 +373,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
                 idx_s.wait_event(ev_ds)
             if use_hip_index:
                 even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds,
-                                         table_rows(st) if (cells or (fused == "cell" and not shard)) else None,
+                                         table_rows(st) if (cells or fused == "cell") else None,
                                          index_build.cell_query_cap(x.shape[0], st.num_heads), parts_ctx, on_even)
             else:
                 parts = timer.run("index/partition", index_build.stage_partitions, x, off, st.window_size)
@@ -415,7 +420,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
                 states.append(make_stage_state(x, off, st, seed + si))
             state = states[si - first]
             state.xyz, state.offset = x, off
-            started[si] = attention_block(state, even_blk, timer, False if shard else fused, shard)
+            started[si] = attention_block(state, even_blk, timer, fused, shard)
 
     if builder is None:
         index(first, first_block_early if (overlap and use_hip_index and EVEN_FIRST) else None)
@@ -444,7 +449,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         for b in range(st.depth):
             if b == 0 and si in started:
                 continue
-            out = attention_block(state, even if b % 2 == 0 else odd, timer, False if shard else fused, shard)
+            out = attention_block(state, even if b % 2 == 0 else odd, timer, fused, shard)
             if early and b == 0 and builder is None:
                 index(si + 1)
         results.append(dict(stage=si, n=x.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),

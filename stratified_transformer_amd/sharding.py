@@ -135,6 +135,42 @@ class _SharedParam(torch.autograd.Function):
         return _all_reduce_sum(g.contiguous().clone(), ctx.group), None
 
 
+class _Ctx:
+    pass
+
+
+class _ScatterSumRows(torch.autograd.Function):
+    """[N, ...] partial sums on every rank -> this rank's rows [lo:hi) of their sum (reduce-scatter); backward: the ranks' row
+    gradients gathered into the full tensor (all-gather).  The mirror image of _GatherRows, built from its two halves."""
+
+    @staticmethod
+    def forward(ctx, full_partial, bounds, rank, group):
+        ctx.bounds, ctx.rank, ctx.group = bounds, rank, group
+        c = _Ctx()
+        c.bounds, c.rank, c.group = bounds, rank, group
+        return _GatherRows.backward(c, full_partial.contiguous())[0]
+
+    @staticmethod
+    def backward(ctx, g_local):
+        return _GatherRows.forward(_Ctx(), g_local.contiguous(), ctx.bounds, ctx.rank, ctx.group), None, None, None
+
+
+def sharded_cell_attention(cell_attention, plan, bounds, rank, q_local, k_local, v_local, table_q, table_k, table_v, group=None):
+    """The window-centric module (fused.cell_attention) for one scene over several ranks.  The unit of work is a CELL: rank r of w
+    takes every w-th cell of the size-sorted list (CellPlan.share), so the shares are balanced without looking at the geometry.
+    q/k/v_local are the rank's own rows (the same row bounds as sharded_window_attention); all three are all-gathered, the rank
+    computes its cells' output rows, and a reduce-scatter hands every rank the sum's rows it owns.  Backward: grad_out
+    all-gathered, grad_q / grad_k / grad_v reduce-scattered (through the gathers' backward), table gradients all-reduced.
+    Returns out_local [hi-lo, h, 16]; every rank ends with the rows of the single-GPU result and gradient it owns."""
+    world = len(bounds) - 1
+    q_full = _GatherRows.apply(q_local, bounds, rank, group)
+    k_full = _GatherRows.apply(k_local, bounds, rank, group)
+    v_full = _GatherRows.apply(v_local, bounds, rank, group)
+    tq, tk, tv = (_SharedParam.apply(t, group) for t in (table_q, table_k, table_v))
+    part = cell_attention(q_full, k_full, v_full, tq, tk, tv, plan.share(rank, world) if world > 1 else plan)
+    return _ScatterSumRows.apply(part, bounds, rank, group)
+
+
 def sharded_window_attention(ops, shard, bounds, rank, q_local, k_local, v_local, table_q, table_k, table_v, n_max=0,
                              group=None, segment_softmax=None):
     """WindowAttention.forward's op sequence (model/stratified_transformer.py:183-208) for the queries of

@@ -60,6 +60,15 @@ def _worker(rank, world, port, prob, scene_xyz, out_dir):
             res[f"s{si}_index_1"] = r["odd"].index_1.cpu().numpy()
             res[f"s{si}_gq"] = states[si].q.grad.cpu().numpy()
             res[f"s{si}_gtv"] = states[si].tables[2].grad.cpu().numpy()
+        # (3) the same pass with the window-centric kernels on the rank's share of the cells (sharding.sharded_cell_attention)
+        states_c, results_c = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=5, fused="cell", shard=(rank, world))
+        torch.cuda.synchronize()
+        for si, r in enumerate(results_c):
+            res[f"c{si}_rows"] = np.array(r["out_rows"])
+            res[f"c{si}_out"] = r["out"].detach().cpu().numpy()
+            res[f"c{si}_gq"] = states_c[si].q.grad.cpu().numpy()
+            res[f"c{si}_gk"] = states_c[si].k.grad.cpu().numpy()
+            res[f"c{si}_gtk"] = states_c[si].tables[1].grad.cpu().numpy()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     finally:
         dist.destroy_process_group()
@@ -111,3 +120,9 @@ def test_two_ranks_equal_one_rank(tmp_path):
             np.testing.assert_allclose(r[f"s{si}_gq"][lo:hi], n(states[si].q.grad)[lo:hi], **tol)
             np.testing.assert_allclose(r[f"s{si}_gtv"], n(states[si].tables[2].grad), rtol=5e-4, atol=5e-4)
         assert cover[0][0] == 0 and cover[0][1] == cover[1][0] and cover[1][1] == full.shape[0]
+        for r in ranks:  # the cell-sharded pass: the same rows, the same numbers up to the order of the sums
+            lo, hi = (int(x) for x in r[f"c{si}_rows"])
+            np.testing.assert_allclose(r[f"c{si}_out"], full[lo:hi], rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(r[f"c{si}_gq"][lo:hi], n(states[si].q.grad)[lo:hi], rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(r[f"c{si}_gk"][lo:hi], n(states[si].k.grad)[lo:hi], rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(r[f"c{si}_gtk"], n(states[si].tables[1].grad), rtol=5e-4, atol=5e-4)

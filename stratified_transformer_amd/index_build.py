@@ -18,6 +18,7 @@ tests compare it with the oracle on CPU); on the GPU the heavy steps dispatch to
 `use_hip=True` (stratified_transformer_amd/csrc/index.hip).
 """
 import ctypes
+import os
 from dataclasses import dataclass
 
 import torch
@@ -249,10 +250,10 @@ class CellPlan:
 
 def cell_query_cap(n_points, heads):
     """Queries per cell piece: small enough that cells x heads fill the chip's resident waves several times over."""
-    cap = 32
-    while cap > 4 and n_points * heads < 6000 * cap:
-        cap //= 2
-    return cap
+    # measured on the four stages of the S3DIS configuration (points x heads = 300k, 150k, 75k, 37k; tools/bench_cell.py): pieces of 32
+    # queries for the two large ones, 16 for the two small ones (8 / 4 there cost 5-25 % of the backward: every piece flushes its
+    # keys' gradients; 32 there leaves too few pieces for the chip)
+    return 32 if n_points * heads >= 96000 else 16
 
 
 def stage_partitions_hip(xyz, offset, window_size):

@@ -139,6 +139,9 @@ def run_gpu(args, rank, world):
     #  rank, all-gather q / k / v, reduce-scatter of the output - sharding.py)
     out["single_cell"] = single_pass_leg("cell")
     out["results"], out["states"] = out["single_ops"]["results"], states
+    if not shard:  # BASELINE configs 2 ("fwd only") and 3 ("fp32 vs bf16") on the same scene
+        out["single_fwd"] = single_pass_leg("cell_fwd")
+        out["single_bf16"] = single_pass_leg("cell_bf16")
 
     # every component, from passes run again with events around every op (not the timed region)
     timer = pipeline.Timer(True)
@@ -373,6 +376,11 @@ def main():
             return dict(ms_per_step=round(ms, 3), value=round(N_POINTS * scenes / (ms / 1e3), 1))
 
         cell, ops = leg(run["single_cell"]["elapsed"]), leg(run["single_ops"]["elapsed"])
+        extra_legs = {}
+        if "single_fwd" in run:
+            extra_legs["cell_forward_only"] = dict(leg(run["single_fwd"]["elapsed"]), note="BASELINE config 2: the same pass without the blocks' backward")
+            extra_legs["cell_bf16_storage"] = dict(leg(run["single_bf16"]["elapsed"]), note="BASELINE config 3, second leg: q / k / v / tables stored as bf16, "
+                                                   "fp32 arithmetic, outputs and gradient sums (an extension: the reference's operators are fp32-only)")
         comp = component_table(run["timer"], K)
         line = {
             "metric": "points/sec through StratifiedAttention fwd+bwd, 100k-pt scene",
@@ -387,7 +395,7 @@ def main():
                        "parallelism": ("1 scene over %d ranks: cells dealt to the ranks by size order, all-gather q/k/v, reduce-scatter out and dq/dk/dv, all-reduce table grads "
                                        "(operator_api: queries sharded by pair count, all-gather k/v, reduce-scatter dk/dv)" % world)
                        if sharded else "1 scene per rank, no data-path collective"},
-            "single_pass": {"cell": cell, "operator_api": ops,
+            "single_pass": {"cell": cell, "operator_api": ops, **extra_legs,
                             "note": "K passes, each complete before the next starts; cell: attention blocks through fused.cell_attention "
                                     "(window-centric kernels); operator_api: through the reference's five operators (what the unmodified model file calls)"},
             "roofline": attention_roofline(run["single_cell"], run, K, "cell"),

@@ -67,6 +67,7 @@ class StageState:
     v: torch.Tensor = None
     tables: list = field(default_factory=list)
     grad_out: torch.Tensor = None
+    bf16: list = None  # q / k / v / tables stored as bf16 (attention_block(fused="cell_bf16")), made on first use
 
 
 class Timer:
@@ -147,6 +148,19 @@ def attention_block(state, blk, timer, fused=False, shard=None):
     if fused == "cell":
         from . import fused as F
         out = timer.run("attn_fwd/cell", F.cell_attention, q, k, v, tq, tk, tv, blk.cells)
+        timer.run("attn_bwd", out.backward, state.grad_out)
+        return out
+    if fused == "cell_fwd":  # BASELINE config 2: forward only
+        from . import fused as F
+        with torch.no_grad():
+            return timer.run("attn_fwd/cell", F.cell_attention, q, k, v, tq, tk, tv, blk.cells)
+    if fused == "cell_bf16":  # BASELINE config 3, second leg: q / k / v / tables STORED as bf16 (fp32 arithmetic, fp32 out and sums)
+        from . import fused as F
+        if getattr(state, "bf16", None) is None:
+            state.bf16 = [t.detach().to(torch.bfloat16).requires_grad_(True) for t in (q, k, v, tq, tk, tv)]
+        for t in state.bf16:
+            t.grad = None
+        out = timer.run("attn_fwd/cell", F.cell_attention, *state.bf16, blk.cells)
         timer.run("attn_bwd", out.backward, state.grad_out)
         return out
     if fused:
@@ -373,7 +387,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
                 idx_s.wait_event(ev_ds)
             if use_hip_index:
                 even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds,
-                                         table_rows(st) if (cells or fused == "cell") else None,
+                                         table_rows(st) if (cells or str(fused).startswith("cell")) else None,
                                          index_build.cell_query_cap(x.shape[0], st.num_heads), parts_ctx, on_even)
             else:
                 parts = timer.run("index/partition", index_build.stage_partitions, x, off, st.window_size)

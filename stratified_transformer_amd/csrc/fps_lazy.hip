@@ -721,8 +721,9 @@ void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, co
         }
         return;
     }
-    // the workgroups of an element wait for each other: all of a launch must be resident together -> at most 128 per launch
-    const int chunk = std::max(1, 128 / G);
+    // the workgroups of an element wait for each other: all of a launch must be resident together (one workgroup per CU) -> at
+    // most half the device's CUs per launch
+    const int chunk = std::max(1, std::min(128, num_cus() / 2) / G);
     for (int c0 = 0; c0 < b; c0 += chunk) {
         const dim3 grid(G, std::min(chunk, b - c0));
         if (slots <= 8) {

@@ -312,7 +312,7 @@ def test_fps_ties_and_duplicates_over_several_workgroups(P):
     g = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(8), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
     g = np.concatenate([g, g])[np.random.default_rng(9).permutation(2 * len(g))]
     n = len(g)  # 16384
-    for m in (n // 8 + 1, n // 2 + 5, n):
+    for m in (n // 8 + 1, n // 2 + 5, n, n + 9):  # (n + 9: more samples than points, as the reference allows)
         got = _fps(P, g, [n], [m])
         assert np.array_equal(got, ref.furthestsampling(g, np.array([n], np.int32), np.array([m], np.int32))), m
 
@@ -367,6 +367,19 @@ def test_knn_lanes_on_a_lattice_full_of_ties(P):
     for k in (3, 16, 40):
         i_ref, d_ref = ref.knnquery(k, g, q, np.array([len(g)], np.int32), np.array([len(q)], np.int32))
         i_got, d_got = _knn(P, k, g, q, [len(g)], [len(q)])
+        assert np.array_equal(i_got, i_ref) and np.array_equal(d_got, d_ref), k
+
+
+def test_knn_lanes_with_a_batch_element_shorter_than_k(P):
+    """Grid path (m * n >= 2^22) with a batch element of five points: its queries keep the reference's fillers (1e10, first index
+    of the element) in the slots no neighbour fills; the other element is an ordinary cloud."""
+    rng = np.random.default_rng(21)
+    xyz = np.concatenate([rng.random((5, 3), dtype=np.float32), rng.random((6000, 3), dtype=np.float32) + np.float32(2.0)])
+    new_xyz = np.concatenate([xyz[:3], xyz[5:5 + 1500]]).astype(np.float32)
+    offset, new_offset = [5, 6005], [3, 1503]
+    for k in (3, 16):
+        i_ref, d_ref = ref.knnquery(k, xyz, new_xyz, np.asarray(offset, np.int32), np.asarray(new_offset, np.int32))
+        i_got, d_got = _knn(P, k, xyz, new_xyz, offset, new_offset)
         assert np.array_equal(i_got, i_ref) and np.array_equal(d_got, d_ref), k
 
 

@@ -74,6 +74,25 @@ def step_attention_bytes(cfg, results):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+import contextlib
+import gc
+
+
+@contextlib.contextmanager
+def no_gc():
+    """The host enqueues a pass in ~12 of its ~14 ms: a full collection of Python's cyclic garbage collector (tens of ms with the
+    process's millions of live objects; due every few dozen passes) inside a timed region shows up as +2-4 ms per pass of a 20-step
+    leg and not at all in a 5-step one.  Collected before, switched off inside (as a training loop that cares would)."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run), before this
     process touches the GPU, and return their exit code (non-zero if any rank fails or does not join)."""
@@ -119,26 +138,35 @@ def run_gpu(args, rank, world):
     # resident synthetic tensors (q/k/v/tables/grad_out stand in for the Linear layers); created once, not timed
     states, results = pipeline.scene_pass(xyz, offset, cfg, None, None, seed=1234 + (0 if shard else rank), fused="cell", shard=shard)
 
+    def summary(res):
+        """what the report needs of a pass's results (sizes only)"""
+        return [dict(stage=r["stage"], n=r["n"], M_even=r["M_even"], M_odd=r["M_odd"]) for r in res]
+
     def single_pass_leg(fused):
+        # A leg keeps NOTHING of its passes but sizes and event timers: with the tensors of an earlier leg's last pass still alive
+        # (pair lists, outputs) the next leg's backward kernels ran 45 % slower for the whole leg - 16.6 instead of 14.2 ms per
+        # pass at --steps 20 (tools/leg_trace2.py; no device allocations involved: the same kernels on memory the allocator
+        # carved differently).  The tensors the parity checks need come from one more pass after all timed legs.
         nonlocal states
         st, res = states, None
         for _ in range(max(args.warmup, 1)):
             st, res = pipeline.scene_pass(xyz, offset, cfg, st, fused=fused, shard=shard)
         live = pipeline.Timer(True, only=("attn", "fps/", "comm/"))
         barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            st, res = pipeline.scene_pass(xyz, offset, cfg, st, live, fused=fused, shard=shard)
-        barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
+        with no_gc():
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                st, res = pipeline.scene_pass(xyz, offset, cfg, st, live, fused=fused, shard=shard)
+            barrier()
+            elapsed = max_over_ranks(time.perf_counter() - t0)
         states = st
-        return dict(elapsed=elapsed, live=live, results=res)
+        return dict(elapsed=elapsed, live=live, results=summary(res))
 
+    del results
     out["single_ops"] = single_pass_leg(False)
     # (sharded scene: operator_api = queries cut by range, all-gather k / v; cell = every world-th cell of the size-sorted list per
     #  rank, all-gather q / k / v, reduce-scatter of the output - sharding.py)
     out["single_cell"] = single_pass_leg("cell")
-    out["results"], out["states"] = out["single_ops"]["results"], states
     if not shard:  # BASELINE configs 2 ("fwd only") and 3 ("fp32 vs bf16") on the same scene
         out["single_fwd"] = single_pass_leg("cell_fwd")
         out["single_bf16"] = single_pass_leg("cell_bf16")
@@ -163,13 +191,18 @@ def run_gpu(args, rank, world):
         def in_flight_leg(fused):
             pipeline.passes_in_flight([xyz], [offset], cfg, lanes, max(args.warmup, 1), fused=fused, offset_host_list=HOST_OFFS)
             barrier()
-            t0 = time.perf_counter()
-            last = pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=fused, offset_host_list=HOST_OFFS)
-            barrier()
-            return max_over_ranks(time.perf_counter() - t0), last
+            with no_gc():
+                t0 = time.perf_counter()
+                last = pipeline.passes_in_flight([xyz], [offset], cfg, lanes, args.steps, fused=fused, offset_host_list=HOST_OFFS)
+                barrier()
+                return max_over_ranks(time.perf_counter() - t0), last
 
         out["inflight_cell"], last = in_flight_leg("cell")
+        del last
         out["inflight_ops"], last_ops = in_flight_leg(False)
+        # the pass the parity checks refer to: one more single pass through the operators, after everything timed
+        states, out["results"] = pipeline.scene_pass(xyz, offset, cfg, states, fused=False, shard=shard)
+        barrier()
         same = True
         for lane_results in last_ops:
             if lane_results is None:
@@ -178,6 +211,10 @@ def run_gpu(args, rank, world):
                 same = same and torch.equal(a["downsample_idx"], b["downsample_idx"]) and torch.equal(a["even"].index_1, b["even"].index_1) \
                     and torch.equal(a["odd"].rel_idx, b["odd"].rel_idx) and torch.equal(a["out"], b["out"])
         out["inflight_same"] = bool(same)
+    if "results" not in out:
+        states, out["results"] = pipeline.scene_pass(xyz, offset, cfg, states, fused=False, shard=shard)
+        barrier()
+    out["states"] = states
     return out
 
 

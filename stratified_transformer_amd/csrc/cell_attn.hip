@@ -888,7 +888,7 @@ namespace p2 {
 // takes twice as long (tools/cell_trace.py: 16 CUs held -> 31 of 255 workgroups start when the others finish).  The one
 // long-running kernel of this library is the round sampler (16 workgroups per cloud for milliseconds): its launches are noted
 // (common.h, held_cus_*), and while any of them has not finished the grid leaves its shader engines room: workgroups go to
-// the 32 shader engines (8 CUs each) in turn, so one CU less per engine for every 32 held workgroups.  Measured, stage-0
+// the 32 shader engines (8 CUs each) in turn, so one CU per engine is left out (usable_cus(), common.h).  Measured, stage-0
 // forward: 265 us alone, 451 us beside 16 held CUs, 314 us with a grid of 7 per engine (283 us alone with that grid).
 // (Other designs measured: a work queue - contended device-scope atomics, 1.2x slower alone; several workgroups per CU taking
 // contiguous task ranges in dispatch order - the table staging per workgroup and idle waves cost 1.1-1.4x alone; fewer waves

@@ -323,7 +323,9 @@ def cpu_baseline(run):
             idx = ref.furthestsampling(xyz, offset, n_offset)
             xyz, offset = np.ascontiguousarray(xyz[idx]), n_offset
 
-    def stage_seconds(si):
+    kept = {}  # (first warm-up only) the CPU results of every stage, for the parity check against the GPU pass
+
+    def stage_seconds(si, keep=False):
         """everything the unit does at stage si: stratified FPS, both index patterns, depth x block fwd+bwd, TransitionDown FPS + kNN16, Upsample kNN3"""
         st, hs = cfg.stages[si], host[si]
         xyz, offset = hs["xyz"], hs["offset"]
@@ -342,8 +344,11 @@ def cpu_baseline(run):
             a1 = ref.attention_step1_v2(q, k, i1, offs)
             a2 = ref.dot_prod_with_idx_v3(q, offs, k, i1, tq, tk, rel)
             sm = ref.segment_softmax(a1 + a2, offs)
-            ref.attention_step2_with_rel_pos_value_v2(sm, v, offs, i1, tv, rel)
+            o = ref.attention_step2_with_rel_pos_value_v2(sm, v, offs, i1, tv, rel)
             ga, gv, gt = ref.attention_step2_with_rel_pos_value_v2_backward(go, sm, v, offs, i1, tv, rel)
+            if keep and b == st.depth - 1:
+                kept[si] = dict(ds=ds, out=o, blocks=[(blocks[p_]["index_1"].numpy().astype(np.int32), blocks[p_]["offsets"].numpy().astype(np.int32),
+                                                       blocks[p_]["rel_idx"].numpy().astype(np.int32)) for p_ in (0, 1)])  # (unclipped, as the index build emits it)
             gs = ref.segment_softmax_backward(sm, ga, offs)
             ref.attention_step1_v2_backward(gs, q, k, i1, offs)
             ref.dot_prod_with_idx_v3_backward(gs, q, offs, k, i1, tq, tk, rel)
@@ -351,16 +356,39 @@ def cpu_baseline(run):
             n_offset = np.asarray(index_ref.transition_down_offset(offset, cfg.ratio), np.int32)
             idx = ref.furthestsampling(xyz, offset, n_offset)
             n_xyz = np.ascontiguousarray(xyz[idx])
-            ref.knnquery(cfg.k, xyz, n_xyz, offset, n_offset)
+            kidx, _ = ref.knnquery(cfg.k, xyz, n_xyz, offset, n_offset)
             ref.knnquery(cfg.up_k, n_xyz, xyz, n_offset, offset)  # the Upsample kNN between the two stages
+            if keep and si in kept:
+                kept[si]["knn"] = kidx
         return time.perf_counter() - t0
 
-    def step_seconds(stages):
-        return sum(stage_seconds(si) for si in stages)
+    def step_seconds(stages, keep=False):
+        return sum(stage_seconds(si, keep) for si in stages)
 
     full = range(len(cfg.stages))
-    for _ in range(2):
-        step_seconds(full)
+    step_seconds(full, keep=True)
+    step_seconds(full)
+    # parity at full size ("results parity-checked against the GPU output in that run"): every integer tensor of the GPU
+    # pass bit for bit, the last block's output of every stage within 1e-3
+    worst, differ = 0.0, []
+
+    def same(name, got, want):
+        got = got.cpu().numpy()
+        if got.shape != want.shape or not np.array_equal(got, want):
+            differ.append(name)
+
+    for si, r in enumerate(run["results"]):
+        c = kept[si]
+        same("stage%d/downsample_idx" % si, r["downsample_idx"], c["ds"])
+        for pname, blk, (i1, offs, rel) in zip(("even", "odd"), (r["even"], r["odd"]), c["blocks"]):
+            same("stage%d/%s/index_1" % (si, pname), blk.index_1, i1)
+            same("stage%d/%s/offsets" % (si, pname), blk.offsets, offs)
+            same("stage%d/%s/rel_idx" % (si, pname), blk.rel_idx, rel)
+        if "knn" in c and "transition_knn" in r:
+            same("stage%d/transition_knn" % si, r["transition_knn"], c["knn"])
+        worst = max(worst, float(np.abs(r["out"].detach().cpu().numpy() - c["out"]).max()))
+    ints_ok = not differ
+    kept.clear()
     times = sorted(step_seconds(full) for _ in range(5))
     med = times[2]
     # 1-thread figure on a sub-sample: stages 2 and 3 of the same step, all-core time of the same sub-sample beside it
@@ -370,6 +398,7 @@ def cpu_baseline(run):
     sub_one = step_seconds(sub)
     ref.set_num_threads(cores)
     return dict(value=round(N_POINTS / med, 1), unit="points/s", cores=cores, kind="port",
+                parity_at_full_size=bool(ints_ok and worst < 1e-3), integers_bit_identical=bool(ints_ok), integer_tensors_that_differ=differ, max_abs_output_difference=float("%.3g" % worst),
                 sample="the full step (all 4 stages of the same 100k-point scene, every op incl. index build and FPS): 2 warm-ups, median of 5 "
                        "repetitions on %d OpenMP threads; times %s s" % (cores, [round(t, 2) for t in times]),
                 seconds=round(med, 2),

@@ -10,13 +10,14 @@ xyz = torch.from_numpy(scene.make_room(100000, 0)).cuda()
 off = torch.tensor([100000], dtype=torch.int32, device="cuda")
 lanes = []
 NL = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+FUSED = "cell" if os.environ.get("SPAN_CELL", "1") == "1" else False
 for li in range(NL):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        st, _ = pipeline.scene_pass(xyz, off, cfg, lane=li)
+        st, _ = pipeline.scene_pass(xyz, off, cfg, lane=li, fused=FUSED)
     lanes.append((s, st))
 torch.cuda.synchronize()
-pipeline.passes_in_flight([xyz], [off], cfg, lanes, NL, offset_host_list=[[100000]])
+pipeline.passes_in_flight([xyz], [off], cfg, lanes, NL, fused=FUSED, offset_host_list=[[100000]])
 torch.cuda.synchronize()
 marks = []
 calls = []
@@ -66,7 +67,7 @@ def traced(*a, **k):
 pipeline.scene_pass_phases = traced
 # finer: time the first statements of a pass
 t0 = time.perf_counter()
-pipeline.passes_in_flight([xyz], [off], cfg, lanes, int(sys.argv[1]) if len(sys.argv) > 1 else 6, offset_host_list=[[100000]])
+pipeline.passes_in_flight([xyz], [off], cfg, lanes, int(sys.argv[1]) if len(sys.argv) > 1 else 6, fused=FUSED, offset_host_list=[[100000]])
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()

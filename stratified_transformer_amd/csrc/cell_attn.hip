@@ -722,9 +722,8 @@ struct CellTableGeo {
 };
 
 template <int TA, bool BYKEY, typename XT>
-__global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ wbuf,
-                                                                        size_t plane, const XT *__restrict__ X,
-                                                                        float *__restrict__ grad_table) {
+__device__ __forceinline__ void cell_table_grad_body(const pointops2_cell_plan &pl, int h, int L, const float *__restrict__ wbuf, size_t plane,
+                                                     const XT *__restrict__ X, float *__restrict__ grad_table) {
     constexpr int D = 16;
     constexpr int MAXP = BYKEY ? 4 : 8;  // passes of 16 entries per row a segment holds in registers (a key's column is short)
     using G = CellTableGeo<TA>;
@@ -877,6 +876,26 @@ __global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops
     }
 }
 
+template <int TA, bool BYKEY, typename XT>
+__global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ wbuf,
+                                                                        size_t plane, const XT *__restrict__ X,
+                                                                        float *__restrict__ grad_table) {
+    cell_table_grad_body<TA, BYKEY, XT>(pl, h, L, wbuf, plane, X, grad_table);
+}
+
+// the three table gradients of a block as ONE grid (blockIdx.z: 0 = key side, the longest, first in dispatch order; 1 = query side;
+// 2 = value side): each of them alone is short of independent work on the small stages, together they overlap
+template <int TA, typename T>
+__global__ __launch_bounds__(CT_WAVES * 64) void cell_table_grad3_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ gsbuf,
+                                                                         const float *__restrict__ pbuf, size_t plane,
+                                                                         const T *__restrict__ q, const T *__restrict__ k,
+                                                                         const float *__restrict__ grad_out, float *__restrict__ gtq,
+                                                                         float *__restrict__ gtk, float *__restrict__ gtv) {
+    if (blockIdx.z == 0) cell_table_grad_body<TA, true, T>(pl, h, L, gsbuf, plane, k, gtk);
+    else if (blockIdx.z == 1) cell_table_grad_body<TA, false, T>(pl, h, L, gsbuf, plane, q, gtq);
+    else cell_table_grad_body<TA, false, float>(pl, h, L, pbuf, plane, grad_out, gtv);
+}
+
 static int device_cus() { return num_cus(); }
 #ifdef CA_TRACE
 } // namespace p2
@@ -942,6 +961,17 @@ static void launch_cell_bwd(const pointops2_cell_plan *plan, int h, int hdim, in
     // the three table gradients read p / gs only
     const int gx_t = cell_grid_x(2, plan->n_cells, h, CT_WAVES);
     const dim3 tgrid(gx_t, h), tblock(CT_WAVES * 64);
+    // one grid for the three (P2_CELL_TABLE3=0: three launches in a row): backward of a block 10-120 us shorter, most on the small stages
+    static const bool one_grid = getenv("P2_CELL_TABLE3") == nullptr || atoi(getenv("P2_CELL_TABLE3")) != 0;
+    if (one_grid) {
+        const dim3 grid3(gx_t, h, 3);
+        if (L <= 64) hipLaunchKernelGGL((cell_table_grad3_kernel<4, T>), grid3, tblock, CellTableGeo<4>::lds_bytes(), st, *plan, h, L, gsbuf, pbuf, plane, q, k, grad_out,
+                                        grad_table_q, grad_table_k, grad_table_v);
+        else hipLaunchKernelGGL((cell_table_grad3_kernel<5, T>), grid3, tblock, CellTableGeo<5>::lds_bytes(), st, *plan, h, L, gsbuf, pbuf, plane, q, k, grad_out,
+                                grad_table_q, grad_table_k, grad_table_v);
+        check_launch();
+        return;
+    }
     if (L <= 64) {
         using G = CellTableGeo<4>;
         hipLaunchKernelGGL((cell_table_grad_kernel<4, false, T>), tgrid, tblock, G::lds_bytes(), st, *plan, h, L, gsbuf, plane, q, grad_table_q);

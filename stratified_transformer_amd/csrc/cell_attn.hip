@@ -34,7 +34,10 @@ typedef float __attribute__((ext_vector_type(4))) f32x4c;
 #ifdef CA_TRACE
 __device__ unsigned long long ca_trace[3 * 1024];
 #endif
-constexpr int CA_NP = 8;      // forward: passes of 16 keys a lane keeps in registers (128 keys per chunk)
+#ifndef CA_NP_OVERRIDE
+#define CA_NP_OVERRIDE 8
+#endif
+constexpr int CA_NP = CA_NP_OVERRIDE;  // forward: passes of 16 keys a lane keeps in registers (128 keys per chunk)
 constexpr int CA_NP_BWD = 3;  // backward: 48 keys per chunk (key rows AND their gradient accumulators in registers; chunks simply add up)
 #ifndef CA_WAVES_OVERRIDE
 #define CA_WAVES_OVERRIDE 12

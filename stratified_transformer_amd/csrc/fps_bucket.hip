@@ -134,7 +134,10 @@ __global__ void fps_gather_kernel(int N, int b, int Bref, int log2B, const float
 // takes over from the verified prefix.
 constexpr int VER_T = 256;
 
-// thresholds: T[j] = key of point j after samples 0..j-1, for j in [jlo, jhi)
+// thresholds: T[j] = key of point j after samples 0..j-1, for j in [jlo, jhi).  A workgroup = 64 points x 4 waves: wave sl takes
+// the sl-th quarter of every 256-sample tile, the four partial minima meet in LDS (one point per thread left the chip three
+// quarters empty at 25 000 points: 98 workgroups, every thread a chain of 6 000 dependent steps).
+constexpr int VER_P = 64;  // points per workgroup of the threshold / rebuild kernels
 __global__ __launch_bounds__(VER_T) void fps_verify_threshold_kernel(int Bref, int log2B, int jlo, const float *__restrict__ xyz,
                                                                      const int *__restrict__ offset, const int *__restrict__ new_offset,
                                                                      const int *__restrict__ first_bad, unsigned long long *__restrict__ T) {
@@ -143,10 +146,12 @@ __global__ __launch_bounds__(VER_T) void fps_verify_threshold_kernel(int Bref, i
     const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
     const int m = min(end_m - start_m, end_n - start_n);  // the identity prefix cannot be longer than the cloud
     if (first_bad[bid] < jlo) return;
-    const int j = jlo + blockIdx.x * VER_T + threadIdx.x;
+    const int p = threadIdx.x & (VER_P - 1), sl = threadIdx.x / VER_P;
+    const int j = jlo + blockIdx.x * VER_P + p;
     __shared__ float4 s4[VER_T];
-    const int jmax = min(jlo + (int)(blockIdx.x + 1) * VER_T, m);  // tiles of samples needed by this block: i < jmax
-    if (jlo + (int)blockIdx.x * VER_T >= m) return;
+    __shared__ float smin[VER_T / VER_P][VER_P];
+    const int jmax = min(jlo + (int)(blockIdx.x + 1) * VER_P, m);  // tiles of samples needed by this block: i < jmax
+    if (jlo + (int)blockIdx.x * VER_P >= m) return;
     float px = 0.f, py = 0.f, pz = 0.f;
     if (j < m) { px = xyz[(size_t)(start_n + j) * 3]; py = xyz[(size_t)(start_n + j) * 3 + 1]; pz = xyz[(size_t)(start_n + j) * 3 + 2]; }
     float D = 1e10f;
@@ -156,16 +161,27 @@ __global__ __launch_bounds__(VER_T) void fps_verify_threshold_kernel(int Bref, i
         if (i < jmax) s4[threadIdx.x] = make_float4(xyz[(size_t)(start_n + i) * 3], xyz[(size_t)(start_n + i) * 3 + 1], xyz[(size_t)(start_n + i) * 3 + 2], 0.f);
         __syncthreads();
         const int lim = min(VER_T, j - i0);  // samples i < j
+        const int t1 = min(lim, (sl + 1) * VER_P);
 #pragma unroll 8
-        for (int t = 0; t < lim; t++) {
+        for (int t = sl * VER_P; t < t1; t++) {
             const float4 sp = s4[t];
             D = fminf(D, sqd(px - sp.x, py - sp.y, pz - sp.z));
         }
     }
-    if (j < m) T[start_n + j] = ((unsigned long long)__float_as_uint(D) << 32) | (unsigned)key_of(0.f, j, Bref, log2B);
+    smin[sl][p] = D;
+    __syncthreads();
+    if (sl == 0 && j < m) {
+#pragma unroll
+        for (int w = 1; w < VER_T / VER_P; w++) D = fminf(D, smin[w][p]);
+        T[start_n + j] = ((unsigned long long)__float_as_uint(D) << 32) | (unsigned)key_of(0.f, j, Bref, log2B);
+    }
 }
 
-// scan: every point x checks key_x(j) <= T[j] for j in [jlo, jhi); first violation -> first_bad (atomic min)
+// scan: every point x checks key_x(j) <= T[j] for j in [jlo, jhi); first violation -> first_bad (atomic min).
+// 64 points x 4 waves per workgroup like the threshold kernel, but the check of step j needs the minimum over ALL samples before j:
+// per 256-sample tile, wave sl first takes the minimum over its quarter (no checks), the quarters meet in LDS, then it walks its
+// quarter again from min(everything before the tile, the earlier quarters) with the checks - twice the distance evaluations for
+// four times the workgroups.
 __global__ __launch_bounds__(VER_T) void fps_verify_scan_kernel(int Bref, int log2B, int jlo, int jhi_cap, const float *__restrict__ xyz,
                                                                 const int *__restrict__ offset, const int *__restrict__ new_offset,
                                                                 const unsigned long long *__restrict__ T, int *__restrict__ first_bad) {
@@ -174,16 +190,18 @@ __global__ __launch_bounds__(VER_T) void fps_verify_scan_kernel(int Bref, int lo
     const int start_m = bid == 0 ? 0 : new_offset[bid - 1], end_m = new_offset[bid];
     const int n = end_n - start_n;
     const int m = min(min(end_m - start_m, n), jhi_cap);
-    if (first_bad[bid] < jlo || (int)blockIdx.x * VER_T >= n) return;
-    const int x = blockIdx.x * VER_T + threadIdx.x;
+    if (first_bad[bid] < jlo || (int)blockIdx.x * VER_P >= n) return;
+    const int p = threadIdx.x & (VER_P - 1), sl = threadIdx.x / VER_P;
+    const int x = blockIdx.x * VER_P + p;
     __shared__ float4 s4[VER_T];
     __shared__ unsigned long long sT[VER_T];
+    __shared__ float smin[VER_T / VER_P][VER_P];
     __shared__ int s_fb;
     float px = 0.f, py = 0.f, pz = 0.f;
     const bool live = x < n;
     if (live) { px = xyz[(size_t)(start_n + x) * 3]; py = xyz[(size_t)(start_n + x) * 3 + 1]; pz = xyz[(size_t)(start_n + x) * 3 + 2]; }
     const unsigned rk = (unsigned)key_of(0.f, x, Bref, log2B);
-    float D = 1e10f;
+    float Dprev = 1e10f;  // minimum over the samples of all earlier tiles
     int bad = 0x7fffffff;
     // step j uses samples 0..j-1: tile t holds samples i0..i0+255 and thresholds of steps i0+1..i0+256
     for (int i0 = 0; i0 < m - 1; i0 += VER_T) {
@@ -196,18 +214,32 @@ __global__ __launch_bounds__(VER_T) void fps_verify_scan_kernel(int Bref, int lo
             s4[threadIdx.x] = make_float4(xyz[(size_t)(start_n + i) * 3], xyz[(size_t)(start_n + i) * 3 + 1], xyz[(size_t)(start_n + i) * 3 + 2], 0.f);
             sT[threadIdx.x] = (i + 1 >= jlo) ? T[start_n + i + 1] : ~0ull;
         } else {
-            s4[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-            sT[threadIdx.x] = ~0ull;  // never violated
+            s4[threadIdx.x] = make_float4(1e18f, 1e18f, 1e18f, 0.f);  // (a padded sample is infinitely far away and its threshold never violated)
+            sT[threadIdx.x] = ~0ull;
         }
         __syncthreads();
-        const int lim = min(VER_T, m - 1 - i0);
+        const int t0 = sl * VER_P;
+        float mine = 1e10f;  // this quarter's minimum
+#pragma unroll 8
+        for (int u = 0; u < VER_P; u++) {
+            const float4 sp = s4[t0 + u];
+            mine = fminf(mine, sqd(px - sp.x, py - sp.y, pz - sp.z));
+        }
+        smin[sl][p] = mine;
+        __syncthreads();
+        float D = Dprev;
+#pragma unroll
+        for (int w = 0; w < VER_T / VER_P; w++) {
+            const float o = smin[w][p];
+            D = w < sl ? fminf(D, o) : D;
+            Dprev = fminf(Dprev, o);
+        }
         if (live && bad == 0x7fffffff) {
-            // no early exit inside a tile: eight samples per trip, the LDS reads of a trip are independent of its
-            // compares (with a break after every sample each trip waited a full LDS round trip)
-            for (int t0 = 0; t0 < lim; t0 += 8) {
+            // no early exit inside a quarter: eight samples per trip, the LDS reads of a trip are independent of its compares
+            for (int u0 = 0; u0 < VER_P; u0 += 8) {
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int t = t0 + u;  // t < VER_T always (VER_T % 8 == 0); padded entries cannot fail
+                    const int t = t0 + u0 + u;
                     const float4 sp = s4[t];
                     D = fminf(D, sqd(px - sp.x, py - sp.y, pz - sp.z));
                     const unsigned long long key = ((unsigned long long)__float_as_uint(D) << 32) | rk;
@@ -237,9 +269,11 @@ __global__ __launch_bounds__(VER_T) void fps_rebuild_kernel(const float *__restr
     const int n = end_n - start_n;
     const int prev = prev_offset ? prev_offset[bid] - (bid == 0 ? 0 : prev_offset[bid - 1]) : 0;
     const int v = first_bad[bid];
-    if (v <= prev || v <= 1 || (int)blockIdx.x * VER_T >= n) return;
-    const int x = blockIdx.x * VER_T + threadIdx.x;
+    if (v <= prev || v <= 1 || (int)blockIdx.x * VER_P >= n) return;
+    const int p = threadIdx.x & (VER_P - 1), sl = threadIdx.x / VER_P;  // 64 points x 4 quarter-tiles (see the threshold kernel)
+    const int x = blockIdx.x * VER_P + p;
     __shared__ float4 s4[VER_T];
+    __shared__ float smin[VER_T / VER_P][VER_P];
     float px = 0.f, py = 0.f, pz = 0.f;
     if (x < n) { px = xyz[(size_t)(start_n + x) * 3]; py = xyz[(size_t)(start_n + x) * 3 + 1]; pz = xyz[(size_t)(start_n + x) * 3 + 2]; }
     float D = 1e10f;
@@ -249,13 +283,20 @@ __global__ __launch_bounds__(VER_T) void fps_rebuild_kernel(const float *__restr
         if (i < v - 1) s4[threadIdx.x] = make_float4(xyz[(size_t)(start_n + i) * 3], xyz[(size_t)(start_n + i) * 3 + 1], xyz[(size_t)(start_n + i) * 3 + 2], 0.f);
         __syncthreads();
         const int lim = min(VER_T, v - 1 - i0);
+        const int t1 = min(lim, (sl + 1) * VER_P);
 #pragma unroll 8
-        for (int t = 0; t < lim; t++) {
+        for (int t = sl * VER_P; t < t1; t++) {
             const float4 sp = s4[t];
             D = fminf(D, sqd(px - sp.x, py - sp.y, pz - sp.z));
         }
     }
-    if (x < n) reinterpret_cast<float *>(pts + inv[start_n + x])[3] = D;
+    smin[sl][p] = D;
+    __syncthreads();
+    if (sl == 0 && x < n) {
+#pragma unroll
+        for (int w = 1; w < VER_T / VER_P; w++) D = fminf(D, smin[w][p]);
+        reinterpret_cast<float *>(pts + inv[start_n + x])[3] = D;
+    }
 }
 
 // ---- sampling --------------------------------------------------------------------------------
@@ -727,13 +768,12 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     static const bool no_verify = getenv("P2_FPS_NO_VERIFY") != nullptr;
     const int *verified = nullptr;
     if (!no_verify) {
-        const int gx = div_up(n, VER_T);
         hipLaunchKernelGGL(fps_verify_init_kernel, dim3(div_up(b, 64)), dim3(64), 0, st, b, offset, new_offset, first_bad);
         hipLaunchKernelGGL(fps_verify_threshold_kernel, dim3(1, b), dim3(VER_T), 0, st, Bref, log2B, 1, xyz, offset, new_offset, first_bad, thr);
-        hipLaunchKernelGGL(fps_verify_scan_kernel, dim3(gx, b), dim3(VER_T), 0, st, Bref, log2B, 1, 64, xyz, offset, new_offset, thr, first_bad);
-        hipLaunchKernelGGL(fps_verify_threshold_kernel, dim3(gx, b), dim3(VER_T), 0, st, Bref, log2B, 64, xyz, offset, new_offset, first_bad, thr);
-        hipLaunchKernelGGL(fps_verify_scan_kernel, dim3(gx, b), dim3(VER_T), 0, st, Bref, log2B, 64, 0x7fffffff, xyz, offset, new_offset, thr, first_bad);
-        hipLaunchKernelGGL(fps_rebuild_kernel, dim3(gx, b), dim3(VER_T), 0, st, xyz, offset, rs.prev_offset, first_bad, inv, pts);
+        hipLaunchKernelGGL(fps_verify_scan_kernel, dim3(div_up(n, VER_P), b), dim3(VER_T), 0, st, Bref, log2B, 1, 64, xyz, offset, new_offset, thr, first_bad);
+        hipLaunchKernelGGL(fps_verify_threshold_kernel, dim3(div_up(n, VER_P), b), dim3(VER_T), 0, st, Bref, log2B, 64, xyz, offset, new_offset, first_bad, thr);
+        hipLaunchKernelGGL(fps_verify_scan_kernel, dim3(div_up(n, VER_P), b), dim3(VER_T), 0, st, Bref, log2B, 64, 0x7fffffff, xyz, offset, new_offset, thr, first_bad);
+        hipLaunchKernelGGL(fps_rebuild_kernel, dim3(div_up(n, VER_P), b), dim3(VER_T), 0, st, xyz, offset, rs.prev_offset, first_bad, inv, pts);
         verified = first_bad;
     }
     const int BSZ = 64 * div_up(n, 64 * FPS_MAX_BUCKETS);

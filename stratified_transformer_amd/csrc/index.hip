@@ -42,12 +42,22 @@ __global__ __launch_bounds__(1024) void bbox_kernel(int N, const float *__restri
     __shared__ float red[6][16];
     const int tid = threadIdx.x;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < N; i += 1024)
-        for (int a = 0; a < 3; a++) {
-            const float v = xyz[(size_t)i * 3 + a];
-            mn[a] = fminf(mn[a], v);
-            mx[a] = fmaxf(mx[a], v);
+    for (int i0 = tid; i0 < N; i0 += 4 * 1024) {  // four points in flight per thread
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = min(i0 + u * 1024, N - 1);  // (past the end: the last point again)
+#pragma unroll
+            for (int a = 0; a < 3; a++) v[u][a] = xyz[(size_t)i * 3 + a];
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                mn[a] = fminf(mn[a], v[u][a]);
+                mx[a] = fmaxf(mx[a], v[u][a]);
+            }
+    }
     for (int a = 0; a < 3; a++) {
         for (int st = 1; st < 64; st <<= 1) {
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], st, 64));

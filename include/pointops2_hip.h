@@ -227,8 +227,15 @@ void pointops2_pairs_fill_launcher(int N, const float *xyz, float window, float 
                                    const int *s_starts, const int *l_cluster, const int *ls, const int *ls_starts, const float *wc,
                                    const int *offsets, int *index_0, int *index_1, int *rel_idx);
 
-/* expands CSR offsets to the per-pair query id (index_0) */
+/* expands CSR offsets to the per-pair query id (index_0); segment bounds are clamped into [0, M], so offsets that do not
+ * describe an M-pair list leave entries unwritten but never write outside index0[0, M) */
 void csr_expand_launcher(int N, int M, const int *offsets, int *index0);
+
+/* *bad (device int) = 0 iff offsets [N+1] describes the per-pair query ids index [M] exactly (offsets[0] = 0,
+ * offsets[N] = M, ordered segments, every pair of segment i carries the id i), non-zero otherwise.  Reads nothing
+ * outside offsets[0..N] and index[0..M) whatever the offsets hold.  index: int32 or int64 (index_is_int64); the model's
+ * scatter_softmax call site (model/stratified_transformer.py:205) passes int64. */
+void pointops2_csr_matches_launcher(int N, int M, const int *offsets, const void *index, int index_is_int64, int *bad);
 
 /* ---- optional fused path (no counterpart in the reference's launcher set) -----------------------
  * attn[m,hh] = softmax over the query's pairs of (<q,k[j]> + <q,Tq(m)> + <k[j],Tk(m)>): A1 + A2 + add + A3 of
@@ -282,6 +289,8 @@ typedef struct pointops2_cell_plan {
     int task_step;           /* ranks: rank r of w takes r, r + w, ... - cells are sorted by size, so the shares are balanced); */
                              /* 0 / 0 (or step 1): all cells.  A partial forward writes only its cells' rows of `out`, a partial */
                              /* backward only its queries' rows of grad_q: zero-fill them and sum over the ranks. */
+    int table_rows;          /* L the packed rel-pos indices of relp were clamped to (pass 2): the attention launchers */
+                             /* reject tables with any other row count (ABI version 2) */
 } pointops2_cell_plan;
 size_t pointops2_cell_plan_workspace_bytes(int N);
 void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_cluster, const int *s_starts, const int *l_cluster,
@@ -299,7 +308,8 @@ void cell_attention_forward_launcher(const pointops2_cell_plan *plan, int h, int
                                      const float *v, const float *table_q, const float *table_k, const float *table_v, float *out,
                                      float *ml, float *pbuf);
 /* Its backward.  out / pbuf = the forward's; gsbuf [h, P] scratch (receives the logit gradients in tile order); grad_q fully
- * written; grad_k, grad_v and the three table gradients are ACCUMULATED (zero-fill them).  L <= 80. */
+ * written; grad_k, grad_v and the three table gradients are ACCUMULATED (zero-fill them).  L <= 80.
+ * Both launchers record an error (pointops2_last_error) unless L == plan->table_rows. */
 void cell_attention_backward_launcher(const pointops2_cell_plan *plan, int h, int hdim, int L, const float *grad_out, const float *q,
                                       const float *k, const float *v, const float *out, const float *table_q, const float *table_k,
                                       const float *table_v, const float *pbuf, float *gsbuf, float *grad_q, float *grad_k,

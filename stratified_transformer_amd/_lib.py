@@ -60,6 +60,7 @@ SIGNATURES = {
     "window_attention_backward_launcher": [I, I, I, I] + [P] * 18,
     "segment_softmax_backward_launcher": [I, I, I, P, P, P, P],
     "csr_expand_launcher": [I, I, P, P],
+    "pointops2_csr_matches_launcher": [I, I, P, P, I, P],
     "pointops2_bbox_launcher": [I, P, P],
     "pointops2_window_partition_launcher": [I, I, P, P, P, F, F, I, P, P, P, P, P, Z],
     "pointops2_window_coord_launcher": [I, P, P, F, I, P],

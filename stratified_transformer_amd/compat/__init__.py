@@ -60,15 +60,16 @@ def scatter_softmax(src, index, dim=-1, eps=1e-12):
     if src.is_cuda and src.dim() == 2 and index.dim() == 1 and d == 0 and src.dtype == torch.float32 and index.numel() > 0:
         from .. import _lib, pointops as P
         # The model calls this right after A1 / A2 on the same pair list (:183-205): the CSR offsets those operators just
-        # used describe `index`.  That is CHECKED on the device (expand the offsets, compare); the verdict is read back -
-        # one host sync, which torch_scatter itself pays for `index.max()` - unless the caller has declared the model's
-        # call order with assume_model_call_order(True): then nothing is read back and a mismatch poisons the result's
-        # first row with NaN instead of taking the generic path.  Either way the offsets are not rebuilt.
+        # used PROBABLY describe `index` - a hint (same device, same M, tensor not written to since), never trusted: one
+        # kernel checks that the offsets tile [0, M) and that every pair of segment i carries the id i (csr_matches; it
+        # cannot read outside the two tensors whatever a stale hint holds).  The verdict is read back - one host sync,
+        # which torch_scatter itself pays for `index.max()` - unless the caller has declared the model's call order with
+        # assume_model_call_order(True): then nothing is read back and a mismatch poisons the result's first row with NaN
+        # instead of taking the generic path (the segment kernels clamp every bound into [0, M], so even then nothing
+        # is read or written out of bounds).  Either way the offsets are not rebuilt.
         offsets = P.last_csr(src.device.index, index.numel())
-        if offsets is not None:
-            expect = torch.empty(index.numel(), dtype=torch.int32, device=src.device)
-            _lib.call("csr_expand_launcher", int(offsets.shape[0]) - 1, int(index.numel()), _lib.ptr(offsets), _lib.ptr(expect), device=src.device)
-            same = (expect == index).all()
+        if offsets is not None and index.dtype in (torch.int32, torch.int64):
+            same = P.csr_matches(offsets, index)
             if _ASSUME_MODEL_ORDER:
                 return P.segment_softmax(src, offsets, same)
             if bool(same):

@@ -926,6 +926,8 @@ static void launch_cell_fwd(const pointops2_cell_plan *plan, int h, int hdim, in
     if (plan == nullptr || plan->n_points <= 0) return;
     if (hdim != 16) { set_error("cell_attention: d != 16"); return; }
     if (L < 1) { set_error("cell_attention: no table rows"); return; }
+    // relp's indices were clamped to [0, plan->table_rows) and L is the axis stride of the LDS table image
+    if (L != plan->table_rows) { set_error("cell_attention: the tables' row count differs from the plan's table_rows"); return; }
     const dim3 block(CA_WAVES * 64);
     const size_t plane = (size_t)plan->n_pairs;
     if (L <= 80) {
@@ -954,6 +956,7 @@ static void launch_cell_bwd(const pointops2_cell_plan *plan, int h, int hdim, in
     if (plan == nullptr || plan->n_points <= 0) return;
     if (hdim != 16) { set_error("cell_attention: d != 16"); return; }
     if (L < 1 || L > 80) { set_error("cell_attention backward: table rows L must be in 1..80"); return; }
+    if (L != plan->table_rows) { set_error("cell_attention backward: the tables' row count differs from the plan's table_rows"); return; }
     hipStream_t st = state().stream;
     const size_t lds = TabGeo<80>::bytes(sizeof(T)) + (size_t)CA_WAVES_BWD * 256 * sizeof(float);
     allow_big_lds(cell_bwd_kernel<CA_NP_BWD, 80, T>, lds);

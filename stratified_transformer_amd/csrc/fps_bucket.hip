@@ -457,14 +457,18 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int Bref, int log2B
                 if ((code >> 6) == s) {
                     int lo = (int)(unsigned)key[s], hi = (int)(unsigned)(key[s] >> 32);
                     int ix = __float_as_int(bx[s]), iy = __float_as_int(by[s]), iz = __float_as_int(bz[s]);
-                    asm volatile("s_mov_b32 m0, %10\n\t"
-                                 "v_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\tv_writelane_b32 %2, %7, m0\n\t"
-                                 "v_writelane_b32 %3, %8, m0\n\tv_writelane_b32 %4, %9, m0"
-                                 : "+v"(lo), "+v"(hi), "+v"(ix), "+v"(iy), "+v"(iz)
+                    // v_writelane_b32 with an SGPR source takes its lane select from m0 on gfx9 (one SGPR per VALU instruction on
+                    // the constant bus; this clang has no __builtin_amdgcn_writelane).  m0 is SAVED and RESTORED inside the
+                    // statement instead of being declared clobbered: no reserved register changes across it.
+                    int m0_saved;
+                    asm volatile("s_mov_b32 %5, m0\n\ts_mov_b32 m0, %11\n\t"
+                                 "v_writelane_b32 %0, %6, m0\n\tv_writelane_b32 %1, %7, m0\n\tv_writelane_b32 %2, %8, m0\n\t"
+                                 "v_writelane_b32 %3, %9, m0\n\tv_writelane_b32 %4, %10, m0\n\t"
+                                 "s_mov_b32 m0, %5"
+                                 : "+v"(lo), "+v"(hi), "+v"(ix), "+v"(iy), "+v"(iz), "=&s"(m0_saved)
                                  : "s"((int)(unsigned)km.key), "s"((int)(unsigned)(km.key >> 32)),
                                    "s"(__builtin_amdgcn_readfirstlane(__float_as_int(cx))), "s"(__builtin_amdgcn_readfirstlane(__float_as_int(cy))),
-                                   "s"(__builtin_amdgcn_readfirstlane(__float_as_int(cz))), "s"(ol)
-                                 : "m0");
+                                   "s"(__builtin_amdgcn_readfirstlane(__float_as_int(cz))), "s"(ol));
                     key[s] = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
                     bx[s] = __int_as_float(ix); by[s] = __int_as_float(iy); bz[s] = __int_as_float(iz);
                 }

@@ -98,12 +98,30 @@ __global__ void interp_bwd_kernel(int n, int c, int k, const float *__restrict__
 }
 
 // ---- CSR helpers ----
-__global__ __launch_bounds__(256) void csr_expand_kernel(int N, const int *__restrict__ offs, int *__restrict__ index0) {
+// The segment bounds are clamped into [0, M]: offsets that do not describe an M-pair list (a caller's mistake, a stale
+// remembered CSR) can then leave entries unwritten but never reach outside index0[0, M).
+__global__ __launch_bounds__(256) void csr_expand_kernel(int N, int M, const int *__restrict__ offs, int *__restrict__ index0) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= N) return;
+    const int s = max(offs[qi], 0), e = min(offs[qi + 1], M);
+    for (int m = s + lane; m < e; m += 64) index0[m] = qi;
+}
+// Does `offs [N+1]` describe the per-pair query ids `index [M]` (ascending runs, run i = query i)?  *bad stays 0 iff
+// offs[0] == 0, offs[N] == M, every segment is ordered and inside [0, M] (=> the segments tile [0, M) exactly) and every
+// pair of segment i carries the id i.  One wave per query; nothing outside offs[0..N] / index[0..M) is touched whatever the
+// offsets hold.  IDX64: the model's index_0 is int64 (model/stratified_transformer.py:205).
+template <typename IndexT>
+__global__ __launch_bounds__(256) void csr_matches_kernel(int N, int M, const int *__restrict__ offs, const IndexT *__restrict__ index,
+                                                          int *__restrict__ bad) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + wave;
     if (qi >= N) return;
     const int s = offs[qi], e = offs[qi + 1];
-    for (int m = s + lane; m < e; m += 64) index0[m] = qi;
+    bool wrong = s < 0 || e > M || s > e || (qi == 0 && s != 0) || (qi == N - 1 && e != M);
+    if (!wrong)
+        for (int m = s + lane; m < e; m += 64) wrong |= index[m] != (IndexT)qi;
+    if (wrong) *bad = 1;  // benign race: every writer stores the same value
 }
 __global__ void iota_kernel(int M, int *v) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,7 +215,7 @@ const char *pointops2_last_error(void) {
     state().error = nullptr;
     return e;
 }
-int pointops2_abi_version(void) { return 1; }
+int pointops2_abi_version(void) { return 2; }  // 2: pointops2_cell_plan.table_rows, pointops2_csr_matches_launcher
 void pointops2_set_table_rows(int L) { state().table_rows = L; }
 void pointops2_set_point_count(int N) { state().total_points = N; }
 void pointops2_set_batch_count(int b) { state().batch_count = b; }
@@ -234,7 +252,19 @@ void interpolation_backward_cuda_launcher(int n, int c, int k, const float *grad
 
 void csr_expand_launcher(int N, int M, const int *offsets, int *index0) {
     if (N <= 0 || M <= 0) return;
-    hipLaunchKernelGGL(csr_expand_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, offsets, index0);
+    hipLaunchKernelGGL(csr_expand_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, M, offsets, index0);
+    check_launch();
+}
+
+void pointops2_csr_matches_launcher(int N, int M, const int *offsets, const void *index, int index_is_int64, int *bad) {
+    hipStream_t st = state().stream;
+    // N == 0 describes M == 0 only; a non-empty pair list needs at least one row
+    if (hipMemsetAsync(bad, (N <= 0 && M > 0) ? 1 : 0, sizeof(int), st) != hipSuccess) { set_error("pointops2_csr_matches: memset failed"); return; }
+    if (N <= 0) return;
+    if (index_is_int64)
+        hipLaunchKernelGGL(csr_matches_kernel<long long>, dim3(div_up(N, 4)), dim3(256), 0, st, N, M, offsets, (const long long *)index, bad);
+    else
+        hipLaunchKernelGGL(csr_matches_kernel<int>, dim3(div_up(N, 4)), dim3(256), 0, st, N, M, offsets, (const int *)index, bad);
     check_launch();
 }
 
@@ -258,7 +288,7 @@ void pointops2_csc_build(int N, int M, const int *index0_offsets, const int *ind
     int *keys = reinterpret_cast<int *>(ws + 2 * seg);
     void *cub_tmp = ws + 3 * seg;
     size_t cub_bytes = workspace_bytes - 3 * seg;
-    hipLaunchKernelGGL(csr_expand_kernel, dim3(div_up(N, 4)), dim3(256), 0, st, N, index0_offsets, index0);
+    hipLaunchKernelGGL(csr_expand_kernel, dim3(div_up(N, 4)), dim3(256), 0, st, N, M, index0_offsets, index0);
     hipLaunchKernelGGL(iota_kernel, dim3(div_up(M, 256)), dim3(256), 0, st, M, iota);
     // stable LSD radix sort: per key the pair ids stay ascending => deterministic summation order
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, index1, keys, (const int *)iota, csc_pair, M, 0, key_bits(NK), st);

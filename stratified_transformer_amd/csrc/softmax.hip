@@ -21,13 +21,13 @@ __device__ __forceinline__ float slot_sum(float v, int hp) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(int N, int h, int hp, const float *__restrict__ src,
+__global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(int N, int M, int h, int hp, const float *__restrict__ src,
                                                               const int *__restrict__ offs, float *__restrict__ out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + wave;
     if (qi >= N) return;
     const int ppw = 64 / hp, p = lane / hp, c = lane % hp;
-    const int s = offs[qi], e = offs[qi + 1];
+    const int s = max(offs[qi], 0), e = min(offs[qi + 1], M);  // never outside [0, M), whatever the offsets hold
     if (e <= s) return;
     for (int hb = 0; hb < h; hb += hp) {
         const int hh = hb + c;
@@ -50,14 +50,14 @@ __global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(int N, int h, int 
 }
 
 // grad_src = y * (grad_y - sum_seg(y * grad_y))
-__global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(int N, int h, int hp, const float *__restrict__ y,
+__global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(int N, int M, int h, int hp, const float *__restrict__ y,
                                                               const float *__restrict__ gy, const int *__restrict__ offs,
                                                               float *__restrict__ gx) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + wave;
     if (qi >= N) return;
     const int ppw = 64 / hp, p = lane / hp, c = lane % hp;
-    const int s = offs[qi], e = offs[qi + 1];
+    const int s = max(offs[qi], 0), e = min(offs[qi + 1], M);  // never outside [0, M), whatever the offsets hold
     if (e <= s) return;
     for (int hb = 0; hb < h; hb += hp) {
         const int hh = hb + c;
@@ -88,13 +88,13 @@ __device__ __forceinline__ float block_combine(float v, int hp, bool is_max, flo
     return r;
 }
 
-__global__ __launch_bounds__(256) void seg_softmax_fwd_block_kernel(int N, int h, int hp, const float *__restrict__ src,
+__global__ __launch_bounds__(256) void seg_softmax_fwd_block_kernel(int N, int M, int h, int hp, const float *__restrict__ src,
                                                                     const int *__restrict__ offs, float *__restrict__ out) {
     __shared__ float red[4 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = blockIdx.x;
     const int ppw = 64 / hp, p = lane / hp + wave * ppw, c = lane % hp, stride = 4 * ppw;
-    const int s = offs[qi], e = offs[qi + 1];
+    const int s = max(offs[qi], 0), e = min(offs[qi + 1], M);  // never outside [0, M), whatever the offsets hold
     if (e <= s) return;
     for (int hb = 0; hb < h; hb += hp) {
         const int hh = hb + c;
@@ -116,14 +116,14 @@ __global__ __launch_bounds__(256) void seg_softmax_fwd_block_kernel(int N, int h
     }
 }
 
-__global__ __launch_bounds__(256) void seg_softmax_bwd_block_kernel(int N, int h, int hp, const float *__restrict__ y,
+__global__ __launch_bounds__(256) void seg_softmax_bwd_block_kernel(int N, int M, int h, int hp, const float *__restrict__ y,
                                                                     const float *__restrict__ gy, const int *__restrict__ offs,
                                                                     float *__restrict__ gx) {
     __shared__ float red[4 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = blockIdx.x;
     const int ppw = 64 / hp, p = lane / hp + wave * ppw, c = lane % hp, stride = 4 * ppw;
-    const int s = offs[qi], e = offs[qi + 1];
+    const int s = max(offs[qi], 0), e = min(offs[qi + 1], M);  // never outside [0, M), whatever the offsets hold
     if (e <= s) return;
     for (int hb = 0; hb < h; hb += hp) {
         const int hh = hb + c;
@@ -154,9 +154,9 @@ extern "C" {
 void segment_softmax_forward_launcher(int N, int M, int h, const float *src, const int *offsets, float *out) {
     if (N <= 0 || M <= 0) return;
     if (few_rows_many_heads(N, h))
-        hipLaunchKernelGGL(seg_softmax_fwd_block_kernel, dim3(N), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), src, offsets, out);
+        hipLaunchKernelGGL(seg_softmax_fwd_block_kernel, dim3(N), dim3(256), 0, state().stream, N, M, h, next_pow2_le64(h), src, offsets, out);
     else
-        hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), src, offsets, out);
+        hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, M, h, next_pow2_le64(h), src, offsets, out);
     check_launch();
 }
 
@@ -164,9 +164,9 @@ void segment_softmax_backward_launcher(int N, int M, int h, const float *out, co
                                        const int *offsets, float *grad_src) {
     if (N <= 0 || M <= 0) return;
     if (few_rows_many_heads(N, h))
-        hipLaunchKernelGGL(seg_softmax_bwd_block_kernel, dim3(N), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), out, grad_out, offsets, grad_src);
+        hipLaunchKernelGGL(seg_softmax_bwd_block_kernel, dim3(N), dim3(256), 0, state().stream, N, M, h, next_pow2_le64(h), out, grad_out, offsets, grad_src);
     else
-        hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, h, next_pow2_le64(h), out, grad_out, offsets, grad_src);
+        hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(div_up(N, 4)), dim3(256), 0, state().stream, N, M, h, next_pow2_le64(h), out, grad_out, offsets, grad_src);
     check_launch();
 }
 

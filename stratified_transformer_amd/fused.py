@@ -109,8 +109,14 @@ class CellAttention(Function):
         L = table_q.shape[0]
         if plan.n_points != N or k.shape[0] != N or v.shape[0] != N:
             raise RuntimeError("cell_attention: the plan was built for %d points, q/k/v have %d/%d/%d rows" % (plan.n_points, N, k.shape[0], v.shape[0]))
-        if L > plan.table_rows:
-            raise RuntimeError("cell_attention: the plan's rel-pos indices were clamped to %d rows, the tables have %d" % (plan.table_rows, L))
+        # The plan's packed rel-pos indices were clamped to [0, plan.table_rows) when it was filled and the kernels take the
+        # tables' L as the axis stride of their LDS image: any other L would index another axis / table (the model asserts the
+        # index range instead, model/stratified_transformer.py:189-190).
+        if L != plan.table_rows:
+            raise RuntimeError("cell_attention: the plan was built for tables of %d rows (cell_table_rows), the tables have %d" % (plan.table_rows, L))
+        if L > 80 and any(ctx.needs_input_grad[:6]):
+            raise RuntimeError("cell_attention: the backward supports at most 80 table rows (L = %d): use the operators of pointops, "
+                               "or run the forward under torch.no_grad()" % L)
         st = q.dtype  # storage type of q / k / v / tables: fp32, or bf16 (fp32 arithmetic and outputs either way)
         if st not in (torch.float32, torch.bfloat16):
             raise TypeError("cell_attention: q / k / v / tables must all be float32 or all bfloat16, got %s" % st)

@@ -195,7 +195,7 @@ class CellPlanStruct(ctypes.Structure):
                 ("n_keyslots", ctypes.c_int), ("counts", ctypes.c_void_p), ("parent_first", ctypes.c_void_p), ("cell_perm", ctypes.c_void_p), ("cell_qstart", ctypes.c_void_p),
                 ("cell_kbase", ctypes.c_void_p), ("cell_pbase", ctypes.c_void_p), ("cell_order", ctypes.c_void_p),
                 ("qcell", ctypes.c_void_p), ("cell_keys", ctypes.c_void_p), ("kcell", ctypes.c_void_p), ("relp", ctypes.c_void_p),
-                ("task_first", ctypes.c_int), ("task_step", ctypes.c_int)]
+                ("task_first", ctypes.c_int), ("task_step", ctypes.c_int), ("table_rows", ctypes.c_int)]
 
 
 @dataclass
@@ -231,7 +231,7 @@ class CellPlan:
             self.struct = CellPlanStruct(self.n_points, self.n_cells, self.n_parents, self.n_pairs, self.n_keyslots, ptr(self.counts),
                                          ptr(self.parent_first), ptr(self.cell_perm), ptr(self.cell_qstart),
                                          ptr(self.cell_kbase), ptr(self.cell_pbase), ptr(self.cell_order), ptr(self.qcell), ptr(self.cell_keys),
-                                         ptr(self.kcell), ptr(self.relp), int(self.task_first), int(self.task_step))
+                                         ptr(self.kcell), ptr(self.relp), int(self.task_first), int(self.task_step), int(self.table_rows))
         return ctypes.byref(self.struct)
 
     @property

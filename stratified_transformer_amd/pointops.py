@@ -110,13 +110,39 @@ _LAST_CSR = {}
 def remember_csr(offsets, M):
     """The CSR offsets the model's A1 / A2 call just used: its next call is scatter_softmax over the same pair list
     (model/stratified_transformer.py:183-205), which only gets the per-pair query ids - compat.scatter_softmax takes the
-    offsets from here instead of rebuilding them (a host sync, a unique and a cumsum per block)."""
-    _LAST_CSR[offsets.device.index] = (offsets, int(M))
+    offsets from here instead of rebuilding them (a host sync, a unique and a cumsum per block).
+
+    Remembered as a HINT only: (tensor, its version, N, M).  The entry keeps the tensor alive (its address cannot be
+    recycled), last_csr() drops it when it was written to since, and the shim verifies on the device that the offsets
+    describe the index it was given (csr_matches) before any kernel walks segments with them."""
+    _LAST_CSR[offsets.device.index] = (offsets, offsets._version, int(offsets.shape[0]) - 1, int(M))
 
 
 def last_csr(device_index, M):
+    """-> offsets [N+1] i32 remembered for this device if they belong to an M-pair list and were not modified since."""
     hit = _LAST_CSR.get(device_index)
-    return hit[0] if hit is not None and hit[1] == int(M) else None
+    if hit is None:
+        return None
+    offsets, version, N, M_seen = hit
+    if M_seen != int(M) or offsets._version != version or int(offsets.shape[0]) - 1 != N:
+        return None
+    return offsets
+
+
+def csr_matches(offsets, index):
+    """0-dim bool device tensor: do `offsets [N+1] i32` describe the per-pair query ids `index [M]` (i32 / i64)?  No host
+    sync; the kernel touches nothing outside the two tensors whatever they hold (csrc/misc.hip csr_matches_kernel)."""
+    _lib.check_tensor(offsets, torch.int32, "offsets")
+    if index.dtype not in (torch.int32, torch.int64):
+        raise TypeError(f"index: expected int32 or int64, got {index.dtype}")
+    index = index.contiguous()
+    if not index.is_cuda or index.device != offsets.device or offsets.dim() != 1 or index.dim() != 1 or offsets.shape[0] < 1:
+        raise RuntimeError("csr_matches: offsets [N+1] and index [M] must be 1-d tensors on the same GPU")
+    bad = torch.empty(1, dtype=torch.int32, device=offsets.device)
+    with torch.cuda.device(offsets.device):
+        _lib.call("pointops2_csr_matches_launcher", int(offsets.shape[0]) - 1, int(index.shape[0]), ptr(offsets), ptr(index),
+                  1 if index.dtype == torch.int64 else 0, ptr(bad), device=offsets.device)
+    return bad[0] == 0
 
 
 def clear_caches():

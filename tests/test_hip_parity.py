@@ -441,6 +441,59 @@ def test_scatter_softmax_shim_on_gpu(P, golden):
     np.testing.assert_allclose(_np(y2), golden["op_a3_out"][_np(perm)], **TOL)
 
 
+def test_scatter_softmax_shim_with_a_stale_remembered_csr(P, golden):
+    """The shim's remembered CSR is a hint: offsets from an EARLIER operator call with the same pair count M but other rows
+    (another N, other segment lengths, or entries far beyond M) must send the call down the generic path - or, with the
+    model's call order declared, poison the first row - and no kernel may touch memory outside its tensors (VERDICT r2 #1:
+    the abort in gpurun_out/r2_gpu_all2.log)."""
+    from stratified_transformer_amd import compat
+    index = dev(golden["blk0_index_0"]).long()
+    src = dev(golden["op_a1_out"] + golden["op_a2_out"])
+    want = golden["op_a3_out"]
+    M, N = int(index.shape[0]), int(golden["blk0_offsets"].shape[0]) - 1
+    good = dev(golden["blk0_offsets"].astype(np.int32))
+    assert bool(P.csr_matches(good, index)) and bool(P.csr_matches(good, index.int()))
+    rng = np.random.default_rng(7)
+    cuts = np.sort(rng.choice(np.arange(1, M), size=N + 6, replace=False))
+    stale = {
+        "same M, other N": np.concatenate([[0], cuts, [M]]).astype(np.int32),
+        "same M, same N, other segment lengths": np.concatenate([[0], cuts[:N - 1], [M]]).astype(np.int32),
+        "does not start at 0": np.concatenate([[5], golden["blk0_offsets"][1:]]).astype(np.int32),
+        "entries far beyond M": (golden["blk0_offsets"].astype(np.int64) * 3).astype(np.int32),
+        "negative and unordered": np.concatenate([[0], -cuts[:N - 1], [M]]).astype(np.int32),
+    }
+    try:
+        for name, offs in stale.items():
+            o = dev(offs)
+            assert not bool(P.csr_matches(o, index)), name
+            P.remember_csr(o, M)
+            assert P.last_csr(0, M) is o
+            compat.assume_model_call_order(False)
+            y = compat.scatter_softmax(src, index, dim=0)                        # verdict read back -> generic / rebuilt offsets
+            np.testing.assert_allclose(_np(y), want, **TOL, err_msg=name)
+            compat.assume_model_call_order(True)
+            y = _np(compat.scatter_softmax(src, index, dim=0))                   # nothing read back -> poisoned first row
+            assert np.isnan(y[0]).all(), name
+        # the true offsets remembered: the segment kernel runs and nothing is poisoned
+        P.remember_csr(good, M)
+        y = _np(compat.scatter_softmax(src, index, dim=0))
+        np.testing.assert_allclose(y, want, **TOL)
+        # a remembered tensor that was written to since is forgotten
+        good.add_(0)
+        assert P.last_csr(0, M) is None
+        # the segment kernels themselves never leave [0, M) with offsets that overshoot
+        y = P.segment_softmax(src, dev(stale["entries far beyond M"]))
+        torch.cuda.synchronize()
+        expand = torch.full((M,), -1, dtype=torch.int32, device="cuda")
+        from stratified_transformer_amd import _lib
+        _lib.call("csr_expand_launcher", N, M, _lib.ptr(dev(stale["entries far beyond M"])), _lib.ptr(expand), device=expand.device)
+        e = _np(expand)
+        assert e.min() >= -1 and e.max() < N
+    finally:
+        compat.assume_model_call_order(False)
+        P.clear_caches()
+
+
 def test_fps_prefix_reuse_and_resume(P):
     """The sampler state kept between calls: shorter request = prefix, longer request = resumed, and both
     equal a from-scratch run (and the oracle)."""
@@ -848,6 +901,40 @@ def test_cell_attention_matches_the_oracle(case):
             tol = TTOL if name.startswith("table") else dict(rtol=2e-5, atol=2e-4)
             scale = max(1.0, float(np.abs(grads[name]).max())) if name.startswith("table") else 1.0
             np.testing.assert_allclose(_np(leaf.grad) / scale, grads[name] / scale, err_msg=f"{case} grad {name}", **tol)
+
+
+def test_cell_attention_rejects_tables_the_plan_was_not_built_for():
+    """The plan's packed rel-pos indices are clamped to [0, plan.table_rows) and L is the axis stride of the kernels' table image:
+    any other L (fewer rows: indices past the image; more rows: another axis) must be an error in Python AND at the C ABI -
+    the model would assert at model/stratified_transformer.py:189-190.  L > 80 has no backward: refused in the forward already
+    when a gradient is required."""
+    import dataclasses
+    from stratified_transformer_amd import _lib, fused
+    n, h, L = 1500, 2, 64
+    _, _, even, _ = _cell_scene(n, 1, 0.16, 0.01, seed=3, L=L, cap=16)
+    plan = even.cells
+    rng = np.random.default_rng(0)
+    mk = lambda rows, grad: [dev(rng.standard_normal((n, h, 16), dtype=np.float32)).requires_grad_(grad) for _ in range(3)] + \
+        [dev(rng.standard_normal((rows, h, 16, 3), dtype=np.float32)).requires_grad_(grad) for _ in range(3)]  # noqa: E731
+    for rows in (L - 8, L + 8):
+        with pytest.raises(RuntimeError, match="table"):
+            fused.cell_attention(*mk(rows, True), plan)
+        # the launcher itself, with the Python check out of the way
+        ops = mk(rows, False)
+        out, ml, pbuf = torch.empty(n, h, 16, device="cuda"), torch.empty(n, h, 2, device="cuda"), torch.empty(h, plan.n_pairs, device="cuda")
+        with pytest.raises(RuntimeError, match="table_rows"):
+            _lib.call("cell_attention_forward_launcher", plan.c_arg(), h, 16, rows, *[_lib.ptr(t) for t in ops], _lib.ptr(out), _lib.ptr(ml), _lib.ptr(pbuf),
+                      device=out.device)
+    # a plan for L = 96 (forward-only size): fine without gradients, refused with them
+    _, _, even96, _ = _cell_scene(n, 1, 0.24, 0.01, seed=3, L=96, cap=16)
+    with torch.no_grad():
+        o = fused.cell_attention(*mk(96, False), even96.cells)
+    assert bool(torch.isfinite(o).all())
+    with pytest.raises(RuntimeError, match="80 table rows"):
+        fused.cell_attention(*mk(96, True), even96.cells)
+    fused.cell_attention(*mk(L, True), plan).sum().backward()   # the matching size still runs
+    torch.cuda.synchronize()
+    assert dataclasses.replace(plan, struct=None).c_arg() is not None
 
 
 # ---- the C ABI with the reference's arguments and allocation pattern alone (SURVEY 8b seam B2) ----------------------

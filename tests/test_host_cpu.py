@@ -152,7 +152,7 @@ def test_library_exports_every_symbol_of_the_header():
     for n in names:
         assert hasattr(l, n), f"{n} declared in include/pointops2_hip.h but not exported"
     assert set(_lib.exported_symbols()) == set(names), set(_lib.exported_symbols()) ^ set(names)
-    assert _lib.lib().pointops2_abi_version() >= 1
+    assert _lib.lib().pointops2_abi_version() >= 2
 
 
 def test_product_path_fails_loudly_without_gpu_tensors():

@@ -250,3 +250,24 @@ def crop_nearest(coord, voxel_max, seed_index):
     """util/data_util.py:188-191"""
     import numpy as np
     return np.argsort(np.sum(np.square(coord - coord[seed_index]), 1), kind="stable")[:voxel_max]
+
+
+def data_prepare(coord, feat, label, split="train", voxel_size=0.04, voxel_max=None, rand=None, seed_index=None, feat_div=255.0):
+    """util/data_util.py:181-203 (data_prepare_v101: feat / 255, :200) and :206-228 (data_prepare_scannet: feat_div = None, :226)
+    without transform / shuffle: shift to the minimum, one point per voxel (`rand` = the loader's per-voxel draw), crop to the
+    voxel_max points nearest to the seed (`seed_index` = the loader's draw for 'train' splits, the middle point otherwise),
+    shift again; -> (coord f32 [n,3], feat f32 [n,3], label i64 [n]).  The arithmetic stays in the coordinates' own dtype,
+    as numpy 1.19.5 (requirements.txt:3) evaluates it."""
+    import numpy as np
+    coord = coord.copy()
+    if voxel_size:
+        coord -= np.min(coord, 0)
+        idx = voxelize(coord, coord.dtype.type(voxel_size), 0, rand)
+        coord, feat, label = coord[idx], feat[idx], label[idx]
+    if voxel_max and label.shape[0] > voxel_max:
+        init = int(seed_index) if "train" in split else label.shape[0] // 2
+        crop = crop_nearest(coord, voxel_max, init)
+        coord, feat, label = coord[crop], feat[crop], label[crop]
+    coord -= np.min(coord, 0)
+    feat = feat.astype(np.float32)
+    return coord.astype(np.float32), feat / np.float32(feat_div) if feat_div else feat, label.astype(np.int64)

@@ -47,3 +47,61 @@ def crop_nearest(coord, voxel_max, seed_index):
     dist = torch.empty(coord.shape[0], dtype=coord.dtype, device=coord.device)
     _lib.call("pointops2_crop_dist_launcher", coord.shape[0], int(coord.dtype == torch.float64), ptr(coord), int(seed_index), ptr(dist), device=coord.device)
     return torch.sort(dist, stable=True)[1][:voxel_max]
+
+
+def data_prepare(coord, feat, label, split="train", voxel_size=0.04, voxel_max=None, rand=None, seed_index=None, feat_div=255.0):
+    """The loaders' per-sample preparation on the device - util/data_util.py:181-203 (`data_prepare_v101`, bound by
+    util/s3dis.py:10: feat / 255) and :206-228 (`data_prepare_scannet`, util/scannet_v2.py:10: feat_div=None) without the
+    host-side transform / shuffle: shift to the minimum, one point per occupied voxel, crop to the `voxel_max` points nearest
+    to a seed point ('train' splits: a random point, else the middle one), shift again.
+    coord [N,3] f32 / f64, feat [N,3], label [N] on the GPU; rand / seed_index replay the loader's two np.random.randint draws
+    (omitted: drawn here).  -> (coord f32, feat f32, label i64), as the loaders return them (:199-201)."""
+    coord = _coord(coord)
+    if voxel_size:
+        coord = coord - coord.min(0)[0]
+        idx = voxelize(coord, voxel_size, 0, rand)
+        coord, feat, label = coord[idx], feat[idx], label[idx]
+    if voxel_max and label.shape[0] > voxel_max:
+        if "train" in split:
+            init = int(torch.randint(0, label.shape[0], (1,))) if seed_index is None else int(seed_index)
+        else:
+            init = label.shape[0] // 2
+        crop = crop_nearest(coord, voxel_max, init)
+        coord, feat, label = coord[crop], feat[crop], label[crop]
+    coord = coord - coord.min(0)[0]
+    feat = feat.float()
+    return coord.float(), feat / feat_div if feat_div else feat, label.long()
+
+
+# ---- readers of the scene files the loaders open (nothing is executed from the file) ----
+def load_s3dis_npy(path, device="cuda"):
+    """util/s3dis.py:37-41: `<room>.npy` holds one [N, 7] array xyzrgbl -> (coord [N,3], feat [N,3] rgb 0..255, label [N]) on
+    `device`, in the file's dtype (np.load with allow_pickle=False)."""
+    import numpy as np
+    data = np.load(path, allow_pickle=False)
+    if data.ndim != 2 or data.shape[1] != 7:
+        raise ValueError(f"{path}: expected an [N, 7] xyzrgbl array, got {data.shape}")
+    t = torch.from_numpy(np.ascontiguousarray(data)).to(device)
+    return t[:, 0:3].contiguous(), t[:, 3:6].contiguous(), t[:, 6].contiguous()
+
+
+def load_scannet_pth(path, device="cuda", with_label=True):
+    """util/scannet_v2.py:41-47: `<scene>.pth` holds the tuple (coord [N,3], feat [N,3], label [N]) of numpy arrays that
+    dataset/scannetv2/prepare_data_inst.py writes with torch.save (test split: no label).  Loaded with weights_only=True -
+    the unpickler may build numpy arrays and nothing else."""
+    import numpy as np
+    allowed = [np.ndarray, np.dtype]
+    try:
+        from numpy._core.multiarray import _reconstruct
+    except ImportError:  # numpy < 2
+        from numpy.core.multiarray import _reconstruct
+    allowed.append(_reconstruct)
+    allowed += [type(np.dtype(t)) for t in (np.float32, np.float64, np.int64, np.int32, np.uint8, np.int16)]
+    with torch.serialization.safe_globals(allowed):
+        data = torch.load(path, map_location="cpu", weights_only=True)
+    if not isinstance(data, (tuple, list)) or len(data) < (3 if with_label else 2):
+        raise ValueError(f"{path}: expected a (coord, feat{', label' if with_label else ''}) tuple")
+    out = [torch.as_tensor(np.ascontiguousarray(np.asarray(a))).to(device) for a in data[: 3 if with_label else 2]]
+    if out[0].dim() != 2 or out[0].shape[1] != 3:
+        raise ValueError(f"{path}: coord must be [N, 3], got {tuple(out[0].shape)}")
+    return tuple(out)

@@ -1237,3 +1237,41 @@ def test_voxelize_and_crop_on_device(dtype):
     seed = len(sub) // 2
     crop = dataprep.crop_nearest(torch.from_numpy(sub).cuda(), 8000, seed)
     assert np.array_equal(crop.cpu().numpy(), index_ref.crop_nearest(sub, 8000, seed))
+
+
+def test_data_prepare_on_device_against_the_reference_golden(tmp_path):
+    """SURVEY 8f-2, pinned to the reference: dataprep.voxel_keys / voxelize / data_prepare on the GPU against
+    tests/golden/voxelize_crop.npz (the reference's util/voxelize.py and util/data_util.py executed by make_golden_dataprep.py:
+    stable argsort, recorded draws), bit for bit - through the readers of the loaders' scene files (.npy [N,7] xyzrgbl,
+    util/s3dis.py:37-41; .pth (coord, feat, label), util/scannet_v2.py:41-47), which are written here in the loaders' formats."""
+    import os
+    from stratified_transformer_amd import dataprep
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "voxelize_crop.npz"))
+    for tag in ("f64", "f32"):
+        coord = g[f"{tag}_coord"]
+        dt = coord.dtype
+        feat, label = g[f"{tag}_feat"].astype(dt), g[f"{tag}_label"].astype(dt)
+        npy, pth = str(tmp_path / f"Area_5_room_{tag}.npy"), str(tmp_path / f"scene_{tag}.pth")
+        np.save(npy, np.concatenate([coord, feat, label[:, None]], 1))
+        torch.save((coord, feat, label), pth)
+        for loader, path, fn, div in ((dataprep.load_s3dis_npy, npy, "data_prepare_v101", 255.0), (dataprep.load_scannet_pth, pth, "data_prepare_scannet", None)):
+            c_d, f_d, l_d = loader(path)
+            assert c_d.is_cuda and c_d.dtype == torch.from_numpy(coord).dtype and np.array_equal(_np(c_d), coord) and np.array_equal(_np(l_d), label)
+            keys = _np(dataprep.voxel_keys(c_d, 0.04)).view(np.uint64)
+            assert np.array_equal(keys, g[f"{tag}_keys"]), tag
+            uniq = dataprep.voxelize(c_d, 0.04, mode=0, rand=dev(g[f"{tag}_train_rand"].astype(np.int64)))
+            assert np.array_equal(_np(uniq), g[f"{tag}_train_idx"]), tag
+            idx_sort, count = dataprep.voxelize(c_d, 0.04, mode=1)
+            assert np.array_equal(_np(idx_sort), g[f"{tag}_val_idx_sort"]) and np.array_equal(_np(count), g[f"{tag}_val_count"]), tag
+            for split in ("val", "train"):
+                key = f"{tag}_{fn}_{split}"
+                seed = int(g[key + "_seed"]) if split == "train" else None
+                c, f, l = dataprep.data_prepare(c_d, f_d, l_d, split, 0.04, 4000, dev(g[key + "_rand"].astype(np.int64)), seed, div)
+                assert c.dtype == torch.float32 and f.dtype == torch.float32 and l.dtype == torch.int64
+                assert np.array_equal(_np(c), g[key + "_coord"]) and np.array_equal(_np(f), g[key + "_feat"]) and np.array_equal(_np(l), g[key + "_label"]), key
+    with pytest.raises(Exception):   # a pickle that wants to build anything but numpy arrays is refused, not executed
+        import pickle
+        bad = str(tmp_path / "bad.pth")
+        with open(bad, "wb") as fh:
+            pickle.dump((os.getcwd,), fh)
+        dataprep.load_scannet_pth(bad)

@@ -253,3 +253,27 @@ def test_stratified_h6_L80_oracle_matches_reference_golden():
     x = ref.attention_step2_with_rel_pos_value_v2(sm, v, offs, i1, g["table_v"], rel)
     y = x.reshape(N, C) @ g["proj_weight"].T + g["proj_bias"]
     np.testing.assert_allclose(y, g["out"], rtol=1e-4, atol=1e-4)
+
+
+def test_voxelize_crop_and_data_prepare_match_reference():
+    """SURVEY 8f-2, pinned: oracle/index_ref.py's voxelize / crop_nearest / data_prepare against tests/golden/voxelize_crop.npz,
+    which make_golden_dataprep.py produced by executing the reference's util/voxelize.py and util/data_util.py (stable argsort,
+    recorded random draws).  Everything bit-exact: keys, indices, counts, cropped coordinates, features, labels."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "voxelize_crop.npz"))
+    for tag in ("f64", "f32"):
+        coord = g[f"{tag}_coord"]
+        dt = coord.dtype
+        feat, label = g[f"{tag}_feat"].astype(dt), g[f"{tag}_label"].astype(dt)
+        vox = dt.type(0.04)
+        assert np.array_equal(index_ref.fnv_hash_vec(np.floor(coord / vox)), g[f"{tag}_keys"]), tag
+        assert np.array_equal(index_ref.voxelize(coord, vox, 0, g[f"{tag}_train_rand"].astype(np.int64)), g[f"{tag}_train_idx"]), tag
+        idx_sort, count = index_ref.voxelize(coord, vox, 1)
+        assert np.array_equal(idx_sort, g[f"{tag}_val_idx_sort"]) and np.array_equal(count, g[f"{tag}_val_count"]), tag
+        for fn, div in (("data_prepare_v101", 255.0), ("data_prepare_scannet", None)):
+            for split in ("val", "train"):
+                key = f"{tag}_{fn}_{split}"
+                seed = int(g[key + "_seed"]) if split == "train" else None
+                c, f, l = index_ref.data_prepare(coord, feat, label, split, 0.04, 4000, g[key + "_rand"].astype(np.int64), seed, div)
+                assert c.dtype == np.float32 and f.dtype == np.float32 and l.dtype == np.int64
+                assert np.array_equal(c, g[key + "_coord"]) and np.array_equal(f, g[key + "_feat"]) and np.array_equal(l, g[key + "_label"]), key

@@ -167,6 +167,8 @@ def run_gpu(args, rank, world):
     # (sharded scene: operator_api = queries cut by range, all-gather k / v; cell = every world-th cell of the size-sorted list per
     #  rank, all-gather q / k / v, reduce-scatter of the output - sharding.py)
     out["single_cell"] = single_pass_leg("cell")
+    if not shard:
+        out["single_model"] = single_pass_leg("model")
     if not shard:  # BASELINE configs 2 ("fwd only") and 3 ("fp32 vs bf16") on the same scene
         out["single_fwd"] = single_pass_leg("cell_fwd")
         out["single_bf16"] = single_pass_leg("cell_bf16")
@@ -214,6 +216,21 @@ def run_gpu(args, rank, world):
     if "results" not in out:
         states, out["results"] = pipeline.scene_pass(xyz, offset, cfg, states, fused=False, shard=shard)
         barrier()
+
+    def capture(res):
+        """the last block's output and six gradients of every stage, as host arrays (attention_block clears .grad per block)"""
+        return [dict(out=r["out"].detach().cpu().numpy(),
+                     grads=[t.grad.detach().float().cpu().numpy() for t in (s_.q, s_.k, s_.v) + tuple(s_.tables)])
+                for r, s_ in zip(res, states)]
+    out["parity"] = {}
+    if not shard:
+        # the pass the parity leg checks, per kernel family: the operators (out["results"], made last above) and - one more pass -
+        # the cell kernels, i.e. the leg that produces `value`
+        out["parity"]["operator_api"] = capture(out["results"])
+        states, res_cell = pipeline.scene_pass(xyz, offset, cfg, states, fused="cell", shard=shard)
+        barrier()
+        out["parity"]["cell"] = capture(res_cell)
+        del res_cell
     out["states"] = states
     return out
 
@@ -244,9 +261,23 @@ def attention_roofline(leg, run, steps, label):
         except (ValueError, OSError):
             traffic = None
     ach = total / ((fwd_ms + bwd_ms) / 1e3) / 1e9 if fwd_ms + bwd_ms > 0 else None
+    # the same per stage (the late stages' fractions are much lower than stage 0's: few points, many heads)
+    f_by, b_by = leg["live"].totals_by_stage("attn_fwd"), leg["live"].totals_by_stage("attn_bwd")
+    stages = []
+    for row in per_stage:
+        si, cfg_st = row["stage"], run["cfg"].stages[row["stage"]]
+        sb = dict(fwd=0, fwd_glue=0, bwd=0)
+        for b in range(cfg_st.depth):
+            for k_, v_ in attention_bytes(row["N"], row["M_even"] if b % 2 == 0 else row["M_odd"], cfg_st.channels, cfg_st.num_heads).items():
+                sb[k_] += v_
+        fm, bm = f_by.get(si, (0.0, 0))[0] / steps, b_by.get(si, (0.0, 0))[0] / steps
+        stages.append(dict(stage=si, blocks=cfg_st.depth, forward_ms=round(fm, 3), backward_ms=round(bm, 3),
+                           forward_ms_per_block=round(fm / cfg_st.depth, 4), backward_ms_per_block=round(bm / cfg_st.depth, 4),
+                           forward_frac=round((sb["fwd"] + sb["fwd_glue"]) / (fm / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if fm else None,
+                           backward_frac=round(sb["bwd"] / (bm / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if bm else None))
     return dict(bound="hbm", kernel="attention blocks, forward+backward (%s)" % label, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                algorithmic_bytes_per_step=int(total), attention_ms_per_step=round(fwd_ms + bwd_ms, 3),
+                algorithmic_bytes_per_step=int(total), attention_ms_per_step=round(fwd_ms + bwd_ms, 3), per_stage=stages,
                 forward=dict(bytes=int(fwd_bytes), ms=round(fwd_ms, 3), frac=round(fwd_bytes / (fwd_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if fwd_ms else None,
                              formula="sum over blocks of 24NC+12N+36M+12Mh (A1,A2,A4) + 20Mh+8M (add, softmax)"),
                 backward=dict(bytes=int(by["bwd"]), ms=round(bwd_ms, 3), frac=round(by["bwd"] / (bwd_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if bwd_ms else None,
@@ -350,8 +381,10 @@ def cpu_baseline(run):
                 kept[si] = dict(ds=ds, out=o, blocks=[(blocks[p_]["index_1"].numpy().astype(np.int32), blocks[p_]["offsets"].numpy().astype(np.int32),
                                                        blocks[p_]["rel_idx"].numpy().astype(np.int32)) for p_ in (0, 1)])  # (unclipped, as the index build emits it)
             gs = ref.segment_softmax_backward(sm, ga, offs)
-            ref.attention_step1_v2_backward(gs, q, k, i1, offs)
-            ref.dot_prod_with_idx_v3_backward(gs, q, offs, k, i1, tq, tk, rel)
+            gq1, gk1 = ref.attention_step1_v2_backward(gs, q, k, i1, offs)
+            gq2, gk2, gtq, gtk = ref.dot_prod_with_idx_v3_backward(gs, q, offs, k, i1, tq, tk, rel)
+            if keep and b == st.depth - 1:
+                kept[si]["grads"] = [gq1 + gq2, gk1 + gk2, gv, gtq, gtk, gt]   # dq dk dv dTq dTk dTv of the stage's last block
         if si < len(cfg.stages) - 1:
             n_offset = np.asarray(index_ref.transition_down_offset(offset, cfg.ratio), np.int32)
             idx = ref.furthestsampling(xyz, offset, n_offset)
@@ -388,6 +421,25 @@ def cpu_baseline(run):
             same("stage%d/transition_knn" % si, r["transition_knn"], c["knn"])
         worst = max(worst, float(np.abs(r["out"].detach().cpu().numpy() - c["out"]).max()))
     ints_ok = not differ
+    # per kernel family (operators / cell kernels = the `value` leg): the last block's output and its six gradients of every stage
+    # against the CPU port.  Outputs: largest absolute difference.  Gradients: largest absolute difference relative to the
+    # tensor's largest entry, and where it occurred.
+    families = {}
+    gnames = ("grad_q", "grad_k", "grad_v", "grad_table_q", "grad_table_k", "grad_table_v")
+    for fam, caps in run.get("parity", {}).items():
+        o_abs, g_rel, g_abs, where = 0.0, 0.0, 0.0, None
+        for si, cap in enumerate(caps):
+            c = kept[si]
+            o_abs = max(o_abs, float(np.abs(cap["out"] - c["out"]).max()))
+            for name, got, want in zip(gnames, cap["grads"], c["grads"]):
+                d = float(np.abs(got - want).max())
+                rel = d / max(float(np.abs(want).max()), 1e-30)
+                g_abs = max(g_abs, d)
+                if rel > g_rel:
+                    g_rel, where = rel, "stage%d/%s" % (si, name)
+        families[fam] = dict(max_abs_output_difference=float("%.3g" % o_abs), max_rel_grad_difference=float("%.3g" % g_rel),
+                             max_abs_grad_difference=float("%.3g" % g_abs), worst_gradient=where,
+                             within_1e_3=bool(o_abs < 1e-3 and g_rel < 1e-3))
     kept.clear()
     times = sorted(step_seconds(full) for _ in range(5))
     med = times[2]
@@ -398,7 +450,9 @@ def cpu_baseline(run):
     sub_one = step_seconds(sub)
     ref.set_num_threads(cores)
     return dict(value=round(N_POINTS / med, 1), unit="points/s", cores=cores, kind="port",
-                parity_at_full_size=bool(ints_ok and worst < 1e-3), integers_bit_identical=bool(ints_ok), integer_tensors_that_differ=differ, max_abs_output_difference=float("%.3g" % worst),
+                parity_at_full_size=bool(ints_ok and worst < 1e-3 and all(f["within_1e_3"] for f in families.values())),
+                integers_bit_identical=bool(ints_ok), integer_tensors_that_differ=differ, max_abs_output_difference=float("%.3g" % worst),
+                parity_by_kernel_family=families,
                 sample="the full step (all 4 stages of the same 100k-point scene, every op incl. index build and FPS): 2 warm-ups, median of 5 "
                        "repetitions on %d OpenMP threads; times %s s" % (cores, [round(t, 2) for t in times]),
                 seconds=round(med, 2),
@@ -442,7 +496,19 @@ def main():
             return dict(ms_per_step=round(ms, 3), value=round(N_POINTS * scenes / (ms / 1e3), 1))
 
         cell, ops = leg(run["single_cell"]["elapsed"]), leg(run["single_ops"]["elapsed"])
+        cell["reached_by"] = ("stratified_transformer_amd.install(fast_layers=True): BasicLayer.forward / WindowAttention.forward of the unmodified model file "
+                              "rebound to stratified_transformer_amd.layers (index built once per stage, fused.cell_attention per block)")
+        ops["reached_by"] = ("the five operators of the drop-in pointops API on a pair list built once per stage (index_build.stage_index_hip): a caller that "
+                             "owns its BasicLayer but keeps the reference's operators")
         extra_legs = {}
+        if "single_model" in run:
+            extra_legs["model_call_order"] = dict(
+                leg(run["single_model"]["elapsed"]),
+                reached_by="stratified_transformer_amd.install() alone: the unmodified BasicLayer / WindowAttention drive the operator API",
+                note="per block the call sequence of WindowAttention.forward (:183-208) with the model's own tensors: int64 indices, fresh .int() copies per "
+                     "operator, rel-pos index by torch ops + two range asserts (host syncs), attn + bias, scatter_softmax shim; the block's pattern is rebuilt "
+                     "for every block beyond the first two (:302-317) with the package's device index build - the model's own torch index build "
+                     "(grid_sample / get_indice_pairs / sort) is NOT in this number (it lives in the model file and cannot run on the GPU box): a lower bound")
         if "single_fwd" in run:
             extra_legs["cell_forward_only"] = dict(leg(run["single_fwd"]["elapsed"]), note="BASELINE config 2: the same pass without the blocks' backward")
             extra_legs["cell_bf16_storage"] = dict(leg(run["single_bf16"]["elapsed"]), note="BASELINE config 3, second leg: q / k / v / tables stored as bf16, "
@@ -462,8 +528,7 @@ def main():
                                        "(operator_api: queries sharded by pair count, all-gather k/v, reduce-scatter dk/dv)" % world)
                        if sharded else "1 scene per rank, no data-path collective"},
             "single_pass": {"cell": cell, "operator_api": ops, **extra_legs,
-                            "note": "K passes, each complete before the next starts; cell: attention blocks through fused.cell_attention "
-                                    "(window-centric kernels); operator_api: through the reference's five operators (what the unmodified model file calls)"},
+                            "note": "K passes, each complete before the next starts; every leg says how a user of the reference reaches it (reached_by)"},
             "roofline": attention_roofline(run["single_cell"], run, K, "cell"),
             "roofline_operator_api": attention_roofline(run["single_ops"], run, K, "operator_api"),
             "fps": fps_report(run["single_cell"], run, K, run["xyz"], run["offset"]),

@@ -291,6 +291,7 @@ typedef struct pointops2_cell_plan {
                              /* backward only its queries' rows of grad_q: zero-fill them and sum over the ranks. */
     int table_rows;          /* L the packed rel-pos indices of relp were clamped to (pass 2): the attention launchers */
                              /* reject tables with any other row count (ABI version 2) */
+    int max_queries;         /* the max_queries the plan was cut with in pass 1 (0 = uncut): sizes the kernels' query tiles */
 } pointops2_cell_plan;
 size_t pointops2_cell_plan_workspace_bytes(int N);
 void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_cluster, const int *s_starts, const int *l_cluster,

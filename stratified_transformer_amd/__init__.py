@@ -5,6 +5,7 @@ windowed sparse-attention hot path, behind the reference's own o
     stratified_transformer_amd.pointops2_cuda  drop-in for the compiled module `pointops2_cuda`
     stratified_transformer_amd.compat          providers of the third-party names the model imports
                                                (torch_scatter.scatter_softmax, torch_geometric.nn.voxel_grid, ...)
+    stratified_transformer_amd.layers          installable fast BasicLayer.forward / WindowAttention.forward (same signatures)
     include/pointops2_hip.h                    the C ABI underneath (libpointops2_hip.so)
 
 `install()` registers the drop-in modules in sys.modules so that the reference's
@@ -21,11 +22,19 @@ def build(verbose=False):
     return _lib.build(verbose=verbose)
 
 
-def install(third_party=True):
+def install(third_party=True, fast_layers=False):
     """Make `import pointops2_cuda`, `from lib.pointops2.functions import pointops` and (optionally) the
-    model's third-party imports resolve to this package."""
+    model's third-party imports resolve to this package.
+
+    fast_layers=True: additionally rebind `BasicLayer.forward` / `WindowAttention.forward` of the (unmodified, importable)
+    `model.stratified_transformer` to the forms of `stratified_transformer_amd.layers`: the stage's index is built once on
+    the device and every attention block runs as one fused function on its cell plan - the path bench.py's headline
+    (`single_pass.cell`) measures.  Without it the model runs on the operator API alone (`single_pass.operator_api`)."""
     from . import pointops2_cuda
     sys.modules.setdefault("pointops2_cuda", pointops2_cuda)
     if third_party:
         from . import compat
         compat.install()
+    if fast_layers:
+        from . import layers
+        return layers.install_fast_layers()

@@ -37,6 +37,7 @@ class WindowAttention(Function):
         M = index1.shape[0]
         L = table_q.shape[0]
         assert table_k.shape[0] == L and table_v.shape[0] == L
+        P._check_pair_list("window_attention", N, index0_offsets, index1, rel_idx)
         pointops_cuda._chk((q, torch.float32, "q"), (k, torch.float32, "k"), (v, torch.float32, "v"),
                            (table_q, torch.float32, "table_q"), (table_k, torch.float32, "table_k"), (table_v, torch.float32, "table_v"),
                            (index0_offsets, torch.int32, "index0_offsets"), (index1, torch.int32, "index1"), (rel_idx, torch.int32, "rel_idx"))

@@ -195,7 +195,7 @@ class CellPlanStruct(ctypes.Structure):
                 ("n_keyslots", ctypes.c_int), ("counts", ctypes.c_void_p), ("parent_first", ctypes.c_void_p), ("cell_perm", ctypes.c_void_p), ("cell_qstart", ctypes.c_void_p),
                 ("cell_kbase", ctypes.c_void_p), ("cell_pbase", ctypes.c_void_p), ("cell_order", ctypes.c_void_p),
                 ("qcell", ctypes.c_void_p), ("cell_keys", ctypes.c_void_p), ("kcell", ctypes.c_void_p), ("relp", ctypes.c_void_p),
-                ("task_first", ctypes.c_int), ("task_step", ctypes.c_int), ("table_rows", ctypes.c_int)]
+                ("task_first", ctypes.c_int), ("task_step", ctypes.c_int), ("table_rows", ctypes.c_int), ("max_queries", ctypes.c_int)]
 
 
 @dataclass
@@ -222,6 +222,7 @@ class CellPlan:
     kcell: torch.Tensor            # [K] i32
     relp: torch.Tensor             # [P] i32 (bit pattern of the packed word)
     struct: CellPlanStruct = None
+    max_queries: int = 0           # the cut of pass 1 (cell_max_queries; 0 = uncut cells)
     task_first: int = 0            # this launch's share of the cells: cell_perm[task_first::task_step] (share(): one scene over ranks)
     task_step: int = 1
 
@@ -231,7 +232,7 @@ class CellPlan:
             self.struct = CellPlanStruct(self.n_points, self.n_cells, self.n_parents, self.n_pairs, self.n_keyslots, ptr(self.counts),
                                          ptr(self.parent_first), ptr(self.cell_perm), ptr(self.cell_qstart),
                                          ptr(self.cell_kbase), ptr(self.cell_pbase), ptr(self.cell_order), ptr(self.qcell), ptr(self.cell_keys),
-                                         ptr(self.kcell), ptr(self.relp), int(self.task_first), int(self.task_step), int(self.table_rows))
+                                         ptr(self.kcell), ptr(self.relp), int(self.task_first), int(self.task_step), int(self.table_rows), int(self.max_queries))
         return ctypes.byref(self.struct)
 
     @property
@@ -289,14 +290,15 @@ def stage_partitions_hip(xyz, offset, window_size):
 
 
 def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_table_rows=None, cell_max_queries=0, partitions=None,
-                    on_even=None):
+                    on_even=None, patterns=(0, 1)):
     """Even and odd block index of one stage, built by the HIP kernels of csrc/index.hip.
 
     xyz [N,3] f32 (GPU), offset [b] i32, downsample_idx [m] i32 -> (BlockIndex even, BlockIndex odd),
     bit-identical to build_block_index() on the same inputs.  cell_table_rows = L: also the cell plan of both
     patterns (BlockIndex.cells) for fused.cell_attention, with the rel-pos indices clamped to [0, L); cell_max_queries > 0
     cuts cells into pieces of at most that many queries (cell_query_cap).  partitions: the result of stage_partitions_hip
-    on the same xyz / offset / window_size, when the caller has already run it."""
+    on the same xyz / offset / window_size, when the caller has already run it.  patterns=(0,) / (1,): only the plain / only the
+    shifted pattern (the other BlockIndex is None) - what ONE block of the unmodified model needs (:302-317 rebuilds per block)."""
     import numpy as np
     from . import _lib
     from ._lib import ptr
@@ -313,7 +315,7 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
     parts, ws, ws_bytes, bbox, w32 = ctx["parts"], ctx["ws"], ctx["ws_bytes"], ctx["bbox"], ctx["w32"]
     with torch.cuda.device(dev):
         sampled = torch.zeros(N, **i32)
-        out = []
+        out = [None, None]   # [plain, shifted]
         pending = []
 
         def finish(pend):
@@ -323,7 +325,7 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
             else:
                 flat = torch.cat([torch.cat([p[5][N:N + 1], p[6]["counts"]]) for p in pend]).tolist()
                 totals = [(flat[9 * i], flat[9 * i + 1:9 * i + 6]) for i in range(len(pend))]
-            for (s, lg, ls, ls_starts, wc, offsets, cells), (M, ccounts) in zip(pend, totals):
+            for (s, lg, ls, ls_starts, wc, offsets, cells, which), (M, ccounts) in zip(pend, totals):
                 index_0, index_1 = torch.empty(M, **i32), torch.empty(M, **i32)
                 rel = torch.empty((M, 3), **i32)
                 call("pointops2_pairs_fill_launcher", N, ptr(xyz), float(w32), _f32(quant_size), ptr(s.cluster), ptr(s.order), ptr(s.starts),
@@ -338,10 +340,13 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
                     call("pointops2_cell_plan_fill_launcher", N, ptr(xyz), float(w32), _f32(quant_size), int(cell_table_rows), ptr(s.order), ptr(ls),
                          ptr(wc), ptr(cells["cell_order"]), ptr(cells["qcell"]), ptr(cells["cell_qstart"]), ptr(cells["cell_desc"]),
                          ptr(cells["cell_kbase"]), ptr(cells["cell_pbase"]), ptr(cell_keys), ptr(kcell), ptr(relp))
-                    plan = CellPlan(N, n_cells, P, K, nk_max, int(cell_table_rows), n_parents, cell_keys=cell_keys, kcell=kcell, relp=relp, **cells)
-                out.append(BlockIndex(index_0, index_1, offsets, counts.max(), rel, None, plan))
+                    plan = CellPlan(N, n_cells, P, K, nk_max, int(cell_table_rows), n_parents, cell_keys=cell_keys, kcell=kcell, relp=relp,
+                                    max_queries=int(cell_max_queries), **cells)
+                out[which] = BlockIndex(index_0, index_1, offsets, counts.max(), rel, None, plan)
 
         for shifted, sname, lname in ((0, "small", "large"), (1, "small_shift", "large_shift")):
+            if shifted not in patterns:
+                continue
             s, lg = parts[sname], parts[lname]
             ls, ls_starts = torch.empty(max(m, 1), **i32), torch.empty(N + 1, **i32)
             call("pointops2_sampled_buckets_launcher", N, m, ptr(downsample_idx), ptr(lg.order), ptr(lg.starts), ptr(lg.n_windows),
@@ -362,7 +367,7 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
                      ptr(cells["cell_order"]), ptr(cells["qcell"]), ptr(cells["cell_desc"]), ptr(cells["cell_qstart"]), ptr(cells["cell_kbase"]),
                      ptr(cells["cell_pbase"]), ptr(cells["cell_perm"]), ptr(cells["parent_first"]), ptr(cells["counts"]), ptr(cws),
                      max(cws_bytes, ws_bytes))
-            pending.append((s, lg, ls, ls_starts, wc, offsets, cells))
+            pending.append((s, lg, ls, ls_starts, wc, offsets, cells, shifted))
             if on_even is not None and shifted == 0:
                 # the caller wants the plain pattern as soon as it exists (its first block runs beside the shifted pattern's
                 # build): one more host sync, the plain pattern ~0.4 ms earlier

@@ -67,6 +67,7 @@ class StageState:
     v: torch.Tensor = None
     tables: list = field(default_factory=list)
     grad_out: torch.Tensor = None
+    window_quant: tuple = None  # (window_size, quant_size) of the stage (model_call_order_block evaluates :186-188 with them)
     bf16: list = None  # q / k / v / tables stored as bf16 (attention_block(fused="cell_bf16")), made on first use
 
 
@@ -78,6 +79,7 @@ class Timer:
         self.enabled = enabled
         self.only = only  # optional tuple of name prefixes: everything else runs untimed
         self.spans = []
+        self.stage = None  # scene_pass notes the stage whose blocks it is enqueueing (per-stage totals)
 
     def run(self, name, fn, *a, **k):
         if not self.enabled or (self.only is not None and not name.startswith(self.only)):
@@ -86,15 +88,24 @@ class Timer:
         e0.record()
         out = fn(*a, **k)
         e1.record()
-        self.spans.append((name, e0, e1))
+        self.spans.append((name, e0, e1, self.stage))
         return out
 
     def totals(self):
         """-> {name: (total_ms, calls)}; call after torch.cuda.synchronize()"""
         out = {}
-        for name, e0, e1 in self.spans:
+        for name, e0, e1, _ in self.spans:
             t, c = out.get(name, (0.0, 0))
             out[name] = (t + e0.elapsed_time(e1), c + 1)
+        return out
+
+    def totals_by_stage(self, prefix):
+        """-> {stage: (total_ms, calls)} of the spans whose name starts with `prefix` and that were enqueued under a noted stage"""
+        out = {}
+        for name, e0, e1, stage in self.spans:
+            if stage is not None and name.startswith(prefix):
+                t, c = out.get(stage, (0.0, 0))
+                out[stage] = (t + e0.elapsed_time(e1), c + 1)
         return out
 
 
@@ -112,7 +123,7 @@ def make_stage_state(xyz, offset, st, seed):
 
     return StageState(xyz, offset, rn(n, h, d), rn(n, h, d), rn(n, h, d),
                       [rn(L, h, d, 3, scale=0.02) for _ in range(3)],
-                      torch.randn(n, h, d, generator=g, device=xyz.device))
+                      torch.randn(n, h, d, generator=g, device=xyz.device), (st.window_size, st.quant_size))
 
 
 def attention_block(state, blk, timer, fused=False, shard=None):
@@ -163,6 +174,8 @@ def attention_block(state, blk, timer, fused=False, shard=None):
         out = timer.run("attn_fwd/cell", F.cell_attention, *state.bf16, blk.cells)
         timer.run("attn_bwd", out.backward, state.grad_out)
         return out
+    if fused == "model":
+        return model_call_order_block(state, blk, timer)
     if fused:
         from . import fused as F
         out = timer.run("attn_fwd/fused", F.window_attention, q, k, v, tq, tk, tv, blk.offsets, blk.index_1, blk.rel_idx)
@@ -173,6 +186,39 @@ def attention_block(state, blk, timer, fused=False, shard=None):
     s = timer.run("attn_fwd/add", torch.add, a1, a2)
     sm = timer.run("attn_fwd/A3", P.segment_softmax, s, blk.offsets)
     out = timer.run("attn_fwd/A4", P.attention_step2_with_rel_pos_value_v2, sm, v, blk.offsets, blk.n_max, blk.index_1, tv, blk.rel_idx)
+    timer.run("attn_bwd", out.backward, state.grad_out)
+    return out
+
+
+def model_call_order_block(state, blk, timer, window_size=None, quant_size=None):
+    """One block the way the UNMODIFIED model file drives the operator API (install() alone, no fast layers) - the call sequence
+    of WindowAttention.forward, model/stratified_transformer.py:183-208, with the tensors the unmodified BasicLayer hands it
+    (:312-319): int64 index_0 / index_1 / offsets, a 0-dim n_max tensor, fresh `.int()` copies for every operator, the rel-pos
+    index evaluated with torch ops and range-checked with two host syncs (:186-190), `attn + bias`, scatter_softmax through the
+    compat shim.  What this leaves out of the model's cost is its own torch index build (grid_sample / get_indice_pairs / sort /
+    bincount, :10-65,:302-317: it lives in the model file and cannot run on the GPU box); scene_pass(fused="model") rebuilds the
+    block's pattern per block with the package's device build instead - a LOWER bound of the model's index cost."""
+    from . import compat
+    q, k, v = state.q, state.k, state.v
+    tq, tk, tv = state.tables
+    xyz = state.xyz
+    index_0, index_1, offsets, n_max = blk.index_0.long(), blk.index_1.long(), blk.offsets.long(), blk.n_max   # as :312-317 leaves them
+    L = tq.shape[0]
+    w, quant = (window_size, quant_size) if window_size is not None else state.window_quant
+
+    def rel_index():
+        rel = xyz[index_0] - xyz[index_1]                                      # :186
+        rel = torch.round(rel * 100000) / 100000                               # :187
+        idx = (rel + 2 * w - 0.0001) // quant                                  # :188
+        assert (idx >= 0).all()                                                # :189 (host sync)
+        assert (idx <= L - 1).all()                                            # :190 (host sync)
+        return idx
+    a1 = timer.run("attn_fwd/A1", P.attention_step1_v2, q.float(), k.float(), index_1.int(), offsets.int(), n_max)
+    rel = timer.run("attn_fwd/rel_idx", rel_index)
+    a2 = timer.run("attn_fwd/A2", P.dot_prod_with_idx_v3, q.float(), offsets.int(), n_max, k.float(), index_1.int(), tq.float(), tk.float(), rel.int())
+    s = timer.run("attn_fwd/add", torch.add, a1, a2)
+    sm = timer.run("attn_fwd/A3", compat.scatter_softmax, s, index_0, 0)
+    out = timer.run("attn_fwd/A4", P.attention_step2_with_rel_pos_value_v2, sm.float(), v.float(), offsets.int(), n_max, index_1.int(), tv.float(), rel.int())
     timer.run("attn_bwd", out.backward, state.grad_out)
     return out
 
@@ -235,6 +281,14 @@ class _IndexBuilder:
         self._thread.join()
         if self._error is not None:
             raise self._error
+
+
+def _block_tensors(blk):
+    """Every device tensor of a block pattern that the attention kernels read: allocated on the index stream, consumed on the main
+    stream - all of them are recorded there (the pair list AND the cell plan: relp, cell_keys, ... - the caching allocator must not
+    hand a plan's block to the next batch's index build while a block's kernels still read it)."""
+    t = (blk.index_0, blk.index_1, blk.offsets, blk.rel_idx, blk.n_max)
+    return t + (tuple(blk.cells.tensors()) if getattr(blk, "cells", None) is not None else ())
 
 
 def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0, cells=False, shard=None):
@@ -395,7 +449,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
                 odd = timer.run("index/pairs", index_build.build_block_index, x, parts["small_shift"], parts["large_shift"], ds, st.window_size, st.quant_size, True)
             ev_idx = torch.cuda.Event()
             ev_idx.record(idx_s)
-        idx_out[si] = (even, odd, ev_idx)
+        idx_out[si] = (even, odd, ev_idx, parts_ctx)
 
     for si in stages:
         geometry(si)
@@ -427,14 +481,16 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         ev.record(torch.cuda.current_stream(dev))  # (the index stream)
         with torch.cuda.stream(main):
             main.wait_event(ev)
-            for t in (x, off, ds, even_blk.index_1, even_blk.offsets, even_blk.rel_idx):
+            for t in (x, off, ds) + _block_tensors(even_blk):
                 if torch.is_tensor(t):
                     t.record_stream(main)
             if make:
                 states.append(make_stage_state(x, off, st, seed + si))
             state = states[si - first]
             state.xyz, state.offset = x, off
+            timer.stage = si
             started[si] = attention_block(state, even_blk, timer, fused, shard)
+            timer.stage = None
 
     if builder is None:
         index(first, first_block_early if (overlap and use_hip_index and EVEN_FIRST) else None)
@@ -443,11 +499,11 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         x, off, _ = clouds[si]
         if builder is not None:
             builder.wait(si)
-        even, odd, ev_idx = idx_out[si]
+        even, odd, ev_idx, parts_ctx = idx_out[si]
         ds, _, knn_idx = geo_out[si]
         if overlap:
             main.wait_event(ev_idx)
-            for t in (x, off, ds, even.index_1, even.offsets, even.rel_idx, odd.index_1, odd.offsets, odd.rel_idx):
+            for t in (x, off, ds) + _block_tensors(even) + _block_tensors(odd):
                 if torch.is_tensor(t):
                     t.record_stream(main)
         if make and si not in started:
@@ -463,7 +519,16 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         for b in range(st.depth):
             if b == 0 and si in started:
                 continue
-            out = attention_block(state, even if b % 2 == 0 else odd, timer, fused, shard)
+            blk_b = even if b % 2 == 0 else odd
+            if fused == "model" and use_hip_index and b >= 2:
+                # the unmodified BasicLayer rebuilds the block's pair list for EVERY block (:302-317); blocks 0 and 1 use the
+                # stage's build above, every further block pays one pattern's build again (on the main stream, as the model would)
+                rebuilt = timer.run("index/rebuild", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds, None, 0,
+                                    parts_ctx, None, (b % 2,))
+                blk_b = rebuilt[b % 2]
+            timer.stage = si
+            out = attention_block(state, blk_b, timer, fused, shard)
+            timer.stage = None
             if early and b == 0 and builder is None:
                 index(si + 1)
         results.append(dict(stage=si, n=x.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),

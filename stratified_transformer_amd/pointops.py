@@ -33,6 +33,21 @@ def _nmax(n_max):
     return n_max if isinstance(n_max, int) else 0
 
 
+def _check_pair_list(op, n_query_rows, offsets, index1, rel_idx=None, per_pair=None):
+    """Shape facts every CSR operator relies on, checked on the host (no sync): the kernels walk `offsets[i] .. offsets[i + 1]`
+    for i < n_query_rows and read index1 / rel_idx / the per-pair operand at those positions, so a pair list whose row count
+    differs from the operand's rows makes them read past `offsets` (a garbage segment end = a wild read: the GPU memory fault of
+    gpurun_out/r3_gpu_all2.log, where a test handed q rows of one cloud to the pair list of another).  The reference checks
+    nothing here (pointops.py:446-482); stricter is compatible."""
+    if offsets.dim() != 1 or int(offsets.shape[0]) - 1 != int(n_query_rows):
+        raise ValueError(f"{op}: the pair list has {int(offsets.shape[0]) - 1} rows (index offsets [{int(offsets.shape[0])}]), the query-side operand {int(n_query_rows)}")
+    M = int(index1.shape[0])
+    if rel_idx is not None and (rel_idx.dim() != 2 or int(rel_idx.shape[0]) != M or int(rel_idx.shape[1]) != 3):
+        raise ValueError(f"{op}: rel_idx must be [{M}, 3], got {tuple(rel_idx.shape)}")
+    if per_pair is not None and int(per_pair.shape[0]) != M:
+        raise ValueError(f"{op}: the per-pair operand has {int(per_pair.shape[0])} rows, the pair list {M} pairs")
+
+
 # ---------------------------------------------------------------------------------------------
 # key-major (CSC) view of a CSR pair list, shared by the backward kernels
 # ---------------------------------------------------------------------------------------------
@@ -367,6 +382,7 @@ class AttentionStep1_v2(Function):
         N_k = k.shape[0]
         M = index1.shape[0]
         C = int(C_div_h * h)
+        _check_pair_list("attention_step1_v2", N_q, index0_offsets, index1)
         output = torch.empty((M, h), dtype=torch.float32, device=q.device)
         # the launcher's N is the number of CSR rows (queries); the reference passes N_k, which is the same
         # number in the model and would be wrong anywhere else (its kernel grid is one block per query)
@@ -517,6 +533,7 @@ class DotProdWithIdx_v3(Function):
         M = index_k.shape[0]
         L = table_q.shape[0]
         assert table_k.shape[0] == L
+        _check_pair_list("dot_prod_with_idx_v3", N, index_q_offsets, index_k, rel_idx)
         output = torch.empty((M, h), dtype=torch.float32, device=q.device)
         pointops_cuda.dot_prod_with_idx_forward_cuda_v3(N, M, h, hdim, _nmax(n_max), q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output)
         remember_csr(index_q_offsets, M)
@@ -585,6 +602,7 @@ class AttentionStep2WithRelPosValue_v2(Function):
         M, h = attn.shape
         N_v, h, hdim = v.shape
         N = int(index0_offsets.shape[0]) - 1  # CSR rows = queries (== N_v in the model, :594-597)
+        _check_pair_list("attention_step2_with_rel_pos_value_v2", N, index0_offsets, index1, rel_idx, attn)
         output = torch.empty((N, h, hdim), dtype=torch.float32, device=v.device)
         pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, _nmax(n_max), attn, v, index0_offsets, index1, table, rel_idx, output)
         ctx.n_max = n_max

@@ -25,8 +25,8 @@ for name in order:
     t1 = time.perf_counter()
     per = []
     for tm in timers:
-        f = sum(e0.elapsed_time(e1) for nme, e0, e1 in tm.spans if nme.startswith("attn_fwd"))
-        b = sum(e0.elapsed_time(e1) for nme, e0, e1 in tm.spans if nme.startswith("attn_bwd"))
+        f = sum(e0.elapsed_time(e1) for nme, e0, e1, _ in tm.spans if nme.startswith("attn_fwd"))
+        b = sum(e0.elapsed_time(e1) for nme, e0, e1, _ in tm.spans if nme.startswith("attn_bwd"))
         per.append((round(f, 2), round(b, 2)))
     print(name, 'avg pass ms %.2f' % ((t1 - t0) / n * 1e3), 'host marks (ms):', [round((m - t0) * 1e3, 1) for m in marks[:6]], '...')
     print('   (fwd, bwd) ms per pass:', per)

@@ -35,7 +35,7 @@ def leg(fused, only, steps=20, warm=5):
     if "res" in keep:
         KEEP.append(res)
     ms = (time.perf_counter() - t0) / steps * 1e3
-    b = sum(e0.elapsed_time(e1) for n, e0, e1 in live.spans if n.startswith("attn_bwd")) / steps if live else float('nan')
+    b = sum(e0.elapsed_time(e1) for n, e0, e1, _ in live.spans if n.startswith("attn_bwd")) / steps if live else float('nan')
     ms1 = torch.cuda.memory_stats()
     print('fused=%-6s only=%-26s pass %.2f ms  attn_bwd %.2f ms | device allocs %d frees %d, reserved %.2f GB allocated %.2f GB' % (
         fused, only, ms, b, ms1["num_device_alloc"] - ms0["num_device_alloc"], ms1["num_device_free"] - ms0["num_device_free"],

@@ -28,16 +28,16 @@
 
 namespace p2 {
 
-constexpr int CM_NKT = 8;  // key tiles (16 keys each) of a chunk
+constexpr int CM_NKT = 8;  // key tiles (16 keys each) of a chunk whose logits stay in registers
 
-template <int LP, int NQT>
+template <int LP>
 struct CmGeo {
-    static constexpr int NTA = LP / 16;             // 16-row tiles per axis
-    static constexpr int RS = LP + 4;               // floats per row of a lookup tile (16-byte aligned rows, banks spread by 4)
-    static constexpr int TILE = 16 * RS;            // floats per lookup tile: 16 queries (or keys) x one axis
-    static constexpr int TAB = 3 * NTA * 256;       // floats per table image in fragment order
-    static constexpr int WAVES = LP <= 64 ? 8 : 6;  // waves per workgroup (LDS: 3 tables + (NQT + 1) lookup tiles per wave)
-    static constexpr int WAVE_FLOATS = (NQT + 1) * TILE;
+    static constexpr int NTA = LP / 16;              // 16-row tiles per axis
+    static constexpr int RS = LP + 4;                // floats per row of a lookup tile (16-byte aligned rows, banks spread by 4)
+    static constexpr int TILE = 16 * RS;             // floats per lookup tile: 16 queries (or keys) x one axis
+    static constexpr int TAB = 3 * NTA * 256;        // floats per table image in fragment order
+    static constexpr int WAVES = LP <= 64 ? 12 : 9;  // waves per workgroup (LDS: 3 tables + 2 lookup tiles per wave; <= 168 registers)
+    static constexpr int WAVE_FLOATS = 2 * TILE;
     static constexpr size_t lds_bytes() { return (size_t)(3 * TAB + WAVES * WAVE_FLOATS) * 4; }
 };
 
@@ -76,21 +76,24 @@ __device__ __forceinline__ void stage_fragments(float *img, const float *__restr
     }
 }
 
-template <int LP, int NQT>
-__global__ __launch_bounds__((CmGeo<LP, NQT>::WAVES * 64)) void cell_fwd_mfma_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ q,
-                                                                                 const float *__restrict__ k, const float *__restrict__ v,
-                                                                                 const float *__restrict__ table_q, const float *__restrict__ table_k,
-                                                                                 const float *__restrict__ table_v, float *__restrict__ out,
-                                                                                 float *__restrict__ pbuf, size_t plane) {
-    using G = CmGeo<LP, NQT>;
+// One wave, one (cell piece, head), 16 queries at a time.  The sweeps over a chunk's key tiles are pipelined by hand: what a step
+// (axis, key tile) needs from memory - the tile's key rows, its packed rel-pos words - is requested one step ahead, so that only
+// the logits of the chunk (4 registers per key tile) live across steps.
+template <int LP>
+__global__ __launch_bounds__((CmGeo<LP>::WAVES * 64)) void cell_fwd_mfma_kernel(pointops2_cell_plan pl, int h, int L, const float *__restrict__ q,
+                                                                                const float *__restrict__ k, const float *__restrict__ v,
+                                                                                const float *__restrict__ table_q, const float *__restrict__ table_k,
+                                                                                const float *__restrict__ table_v, float *__restrict__ out,
+                                                                                float *__restrict__ pbuf, size_t plane) {
+    using G = CmGeo<LP>;
     constexpr int NTA = G::NTA, RS = G::RS, TILE = G::TILE, NKT = CM_NKT;
     extern __shared__ float lds[];
     float *img_q = lds, *img_k = lds + G::TAB, *img_v = lds + 2 * G::TAB;
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int head = blockIdx.y, C = h * 16;
-    float *qtb = lds + 3 * G::TAB + wave * G::WAVE_FLOATS;  // [NQT][16][RS]: QT of one axis, later the weight histogram H (ints)
-    float *ktb = qtb + NQT * TILE;                          // [16][RS]:      KT of one axis for one key tile
+    float *qtb = lds + 3 * G::TAB + wave * G::WAVE_FLOATS;  // [16][RS]: QT of one axis, later the weight histogram H (ints)
+    float *ktb = qtb + TILE;                                // [16][RS]: KT of one axis for one key tile
     stage_fragments<LP, true>(img_q, table_q, L, h, head);
     stage_fragments<LP, true>(img_k, table_k, L, h, head);
     stage_fragments<LP, false>(img_v, table_v, L, h, head);
@@ -110,136 +113,121 @@ __global__ __launch_bounds__((CmGeo<LP, NQT>::WAVES * 64)) void cell_fwd_mfma_ke
         const rsrc_t rs_qid = make_rsrc(pl.cell_order + ct.qs, (unsigned)ct.nq * 4u);
         const rsrc_t rs_p = make_rsrc(pb + ct.pbase, tile_bytes);
         const int nch = (ct.nk + 16 * NKT - 1) / (16 * NKT);
-        // pieces of more than 16 * NQT queries (uncut cells) run as consecutive groups of query tiles
-        for (int i0 = 0; i0 < ct.nq; i0 += 16 * NQT) {
-            float4 qf[NQT];
-            int qid[NQT];
-            bool qok[NQT];
-#pragma unroll
-            for (int qt = 0; qt < NQT; qt++) {
-                const int il = i0 + 16 * qt + n;
-                qok[qt] = il < ct.nq;
-                qid[qt] = (int)bload_u32(rs_qid, il * 4);  // (past the end: 0, never used)
-                qf[qt] = qok[qt] ? ldg4(q + (size_t)qid[qt] * C + hoff) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            f32x4c acc[NQT];
-            float run_m[NQT], run_l[NQT];
-#pragma unroll
-            for (int qt = 0; qt < NQT; qt++) {
-                acc[qt] = zero4;
-                run_m[qt] = -INFINITY;
-                run_l[qt] = 0.f;
-            }
-            // entry (il, jl .. jl + 3) of the tile: byte offset, and how many of the four are inside the tile row
-            auto tile_off = [&](int qt, int j) -> int { return ((i0 + 16 * qt + n) * ct.nk + j) * 4; };
-
-            float lg[NKT][NQT][4];     // logits, then softmax weights, of the chunk: [key tile][query tile][key 4g + t]
-            unsigned w[NKT][NQT][4];   // packed rel-pos words of the same entries
+        // pieces of more than 16 queries run as consecutive groups of 16
+        for (int i0 = 0; i0 < ct.nq; i0 += 16) {
+            const bool qok = i0 + n < ct.nq;
+            const int qid = (int)bload_u32(rs_qid, (i0 + n) * 4);  // (past the end: 0, never used)
+            const float4 qf = qok ? ldg4(q + (size_t)qid * C + hoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int row_off = (i0 + n) * ct.nk * 4;  // byte offset of this lane's query row in the tile
+            f32x4c acc = zero4;                         // out^T: D[feature 4g + t][query n]
+            float run_m = -INFINITY, run_l = 0.f;
+            float lg[NKT][4];                           // logits, then softmax weights: [key tile][key 4g + t] of query n
 
             // ---- sweep 1 of a chunk: logits ----
             auto logits_chunk = [&](int j0, int nkt) {
-                float4 kf[NKT];
+                int keyid[NKT];
 #pragma unroll
-                for (int kt = 0; kt < NKT; kt++)
-                    if (kt < nkt) {
-                        const int key = (int)bload_u32(rs_key, (j0 + 16 * kt + n) * 4);  // (past the end: 0, masked below)
-                        kf[kt] = ldg4(k + (size_t)key * C + hoff);
+                for (int kt = 0; kt < NKT; kt++) keyid[kt] = (int)bload_u32(rs_key, (j0 + 16 * kt + n) * 4);  // (past the end: 0, masked below)
+                float4 kf_nx = ldg4(k + (size_t)keyid[0] * C + hoff);
+                unsigned w_nx[4];
+                bload_words<4>(rs_rel, row_off + (j0 + 4 * g) * 4, w_nx);
+#pragma unroll 1
+                for (int ax = 0; ax < 3; ax++) {  // (a real loop: unrolled, the kernel is 67 KB of code - more than the instruction cache)
 #pragma unroll
-                        for (int qt = 0; qt < NQT; qt++) bload_words<4>(rs_rel, tile_off(qt, j0 + 16 * kt + 4 * g), w[kt][qt]);
+                    for (int T = 0; T < NTA; T++) {
+                        const float4 a = *reinterpret_cast<const float4 *>(img_q + ((ax * NTA + T) * 256 + lane * 4));
+                        const f32x4c d = mfma4(a, qf, zero4);  // D[row 16T + 4g + t][query n]
+                        *reinterpret_cast<f32x4c *>(qtb + n * RS + 16 * T + 4 * g) = d;
                     }
-#pragma unroll
-                for (int kt = 0; kt < NKT; kt++)
-                    if (kt < nkt) {
-#pragma unroll
-                        for (int qt = 0; qt < NQT; qt++) {
-                            const f32x4c s = mfma4(kf[kt], qf[qt], zero4);  // D[key 4g + t][query n]
-#pragma unroll
-                            for (int t = 0; t < 4; t++) lg[kt][qt][t] = s[t];
-                        }
-                    }
-#pragma unroll
-                for (int ax = 0; ax < 3; ax++) {
-#pragma unroll
-                    for (int qt = 0; qt < NQT; qt++)
-#pragma unroll
-                        for (int T = 0; T < NTA; T++) {
-                            const float4 a = *reinterpret_cast<const float4 *>(img_q + ((ax * NTA + T) * 256 + lane * 4));
-                            const f32x4c d = mfma4(a, qf[qt], zero4);  // D[row 16T + 4g + t][query n]
-                            *reinterpret_cast<f32x4c *>(qtb + (qt * 16 + n) * RS + 16 * T + 4 * g) = d;
-                        }
 #pragma unroll
                     for (int kt = 0; kt < NKT; kt++)
                         if (kt < nkt) {
+                            const float4 kf = kf_nx;
+                            unsigned w[4];
+#pragma unroll
+                            for (int t = 0; t < 4; t++) w[t] = w_nx[t];
+                            {   // the next step's inputs: the next key tile of this axis, or the first one of the next axis
+                                const int kn = kt + 1 < nkt ? kt + 1 : 0;
+                                int key_n = keyid[0];
+#pragma unroll
+                                for (int u = 1; u < NKT; u++) key_n = kn == u ? keyid[u] : key_n;
+                                kf_nx = ldg4(k + (size_t)key_n * C + hoff);
+                                bload_words<4>(rs_rel, row_off + (j0 + 16 * kn + 4 * g) * 4, w_nx);
+                            }
+                            if (ax == 0) {
+                                const f32x4c s = mfma4(kf, qf, zero4);  // D[key 4g + t][query n]
+#pragma unroll
+                                for (int t = 0; t < 4; t++) lg[kt][t] = s[t];
+                            }
 #pragma unroll
                             for (int T = 0; T < NTA; T++) {
                                 const float4 a = *reinterpret_cast<const float4 *>(img_k + ((ax * NTA + T) * 256 + lane * 4));
-                                const f32x4c d = mfma4(a, kf[kt], zero4);  // D[row 16T + 4g + t][key n]
+                                const f32x4c d = mfma4(a, kf, zero4);  // D[row 16T + 4g + t][key n]
                                 *reinterpret_cast<f32x4c *>(ktb + n * RS + 16 * T + 4 * g) = d;
                             }
                             lds_fence();
 #pragma unroll
-                            for (int qt = 0; qt < NQT; qt++)
-#pragma unroll
-                                for (int t = 0; t < 4; t++) {
-                                    const int r = (int)((w[kt][qt][t] >> (8 * ax)) & 255u);
-                                    lg[kt][qt][t] += qtb[(qt * 16 + n) * RS + r] + ktb[(4 * g + t) * RS + r];
+                            for (int t = 0; t < 4; t++) {
+                                const int r = (int)((w[t] >> (8 * ax)) & 255u);
+                                lg[kt][t] += qtb[n * RS + r] + ktb[(4 * g + t) * RS + r];
+                                if (ax == 2) {  // entries that are no pair: past the row's end, unused query slots, flagged candidates
+                                    const bool pair = qok && j0 + 16 * kt + 4 * g + t < ct.nk && !(w[t] >> 31);
+                                    lg[kt][t] = pair ? lg[kt][t] : -INFINITY;
                                 }
+                            }
                             __builtin_amdgcn_wave_barrier();  // (the next tile's KT stores stay behind these reads)
                         }
                 }
-                // entries that are no pair: past the tile's end, unused query slots, candidates flagged "not a key of this query"
 #pragma unroll
                 for (int kt = 0; kt < NKT; kt++)
+                    if (kt >= nkt) {
 #pragma unroll
-                    for (int qt = 0; qt < NQT; qt++)
-#pragma unroll
-                        for (int t = 0; t < 4; t++) {
-                            const bool pair = kt < nkt && qok[qt] && j0 + 16 * kt + 4 * g + t < ct.nk && !(w[kt][qt][t] >> 31);
-                            lg[kt][qt][t] = pair ? lg[kt][qt][t] : -INFINITY;
-                        }
+                        for (int t = 0; t < 4; t++) lg[kt][t] = -INFINITY;
+                    }
             };
             // ---- sweep 2 of a chunk: lg holds the softmax weights; out += P V + H Tv ----
             auto values_chunk = [&](int j0, int nkt) {
+                unsigned kid_nx[4];
+                bload_words<4>(rs_key, (j0 + 4 * g) * 4, kid_nx);  // keys 4g .. 4g + 3 of the tile (past the end: 0, weight 0)
 #pragma unroll
                 for (int kt = 0; kt < NKT; kt++)
                     if (kt < nkt) {
-                        unsigned kid[4];
-                        bload_words<4>(rs_key, (j0 + 16 * kt + 4 * g) * 4, kid);  // keys 4g .. 4g + 3 of the tile (past the end: 0, weight 0)
                         float4 vf;  // A[feature n][k-slot (s, g) <-> key 4g + s]
-                        vf.x = v[(size_t)kid[0] * C + head * 16 + n];
-                        vf.y = v[(size_t)kid[1] * C + head * 16 + n];
-                        vf.z = v[(size_t)kid[2] * C + head * 16 + n];
-                        vf.w = v[(size_t)kid[3] * C + head * 16 + n];
-#pragma unroll
-                        for (int qt = 0; qt < NQT; qt++)
-                            acc[qt] = mfma4(vf, make_float4(lg[kt][qt][0], lg[kt][qt][1], lg[kt][qt][2], lg[kt][qt][3]), acc[qt]);  // D[feature 4g + t][query n]
+                        vf.x = v[(size_t)kid_nx[0] * C + head * 16 + n];
+                        vf.y = v[(size_t)kid_nx[1] * C + head * 16 + n];
+                        vf.z = v[(size_t)kid_nx[2] * C + head * 16 + n];
+                        vf.w = v[(size_t)kid_nx[3] * C + head * 16 + n];
+                        if (kt + 1 < nkt) bload_words<4>(rs_key, (j0 + 16 * (kt + 1) + 4 * g) * 4, kid_nx);
+                        acc = mfma4(vf, make_float4(lg[kt][0], lg[kt][1], lg[kt][2], lg[kt][3]), acc);  // D[feature 4g + t][query n]
                     }
                 int *hb = reinterpret_cast<int *>(qtb);
-#pragma unroll
+                unsigned w_nx[4];
+                bload_words<4>(rs_rel, row_off + (j0 + 4 * g) * 4, w_nx);
+#pragma unroll 1
                 for (int ax = 0; ax < 3; ax++) {
-                    for (int x = lane * 4; x < NQT * TILE; x += 256) *reinterpret_cast<int4 *>(hb + x) = make_int4(0, 0, 0, 0);
+                    for (int x = lane * 4; x < TILE; x += 256) *reinterpret_cast<int4 *>(hb + x) = make_int4(0, 0, 0, 0);
                     lds_fence();
 #pragma unroll
                     for (int kt = 0; kt < NKT; kt++)
                         if (kt < nkt) {
+                            unsigned w[4];
 #pragma unroll
-                            for (int qt = 0; qt < NQT; qt++)
+                            for (int t = 0; t < 4; t++) w[t] = w_nx[t];
+                            bload_words<4>(rs_rel, row_off + (j0 + 16 * (kt + 1 < nkt ? kt + 1 : 0) + 4 * g) * 4, w_nx);
 #pragma unroll
-                                for (int t = 0; t < 4; t++) {
-                                    const float p = lg[kt][qt][t];
-                                    if (p != 0.f) atomicAdd(hb + (qt * 16 + n) * RS + (int)((w[kt][qt][t] >> (8 * ax)) & 255u), __float2int_rn(p * 1073741824.f));
-                                }
+                            for (int t = 0; t < 4; t++) {
+                                const float p = lg[kt][t];
+                                if (p != 0.f) atomicAdd(hb + n * RS + (int)((w[t] >> (8 * ax)) & 255u), __float2int_rn(p * 1073741824.f));
+                            }
                         }
                     lds_fence();
 #pragma unroll
-                    for (int qt = 0; qt < NQT; qt++)
-#pragma unroll
-                        for (int T = 0; T < NTA; T++) {
-                            const int4 hv = *reinterpret_cast<const int4 *>(hb + (qt * 16 + n) * RS + 16 * T + 4 * g);  // H[query n][rows 16T + 4g ..]
-                            const float4 a = *reinterpret_cast<const float4 *>(img_v + ((ax * NTA + T) * 256 + lane * 4));
-                            const float sc = 1.0f / 1073741824.f;
-                            acc[qt] = mfma4(a, make_float4((float)hv.x * sc, (float)hv.y * sc, (float)hv.z * sc, (float)hv.w * sc), acc[qt]);
-                        }
+                    for (int T = 0; T < NTA; T++) {
+                        const int4 hv = *reinterpret_cast<const int4 *>(hb + n * RS + 16 * T + 4 * g);  // H[query n][rows 16T + 4g ..]
+                        const float4 a = *reinterpret_cast<const float4 *>(img_v + ((ax * NTA + T) * 256 + lane * 4));
+                        const float sc = 1.0f / 1073741824.f;
+                        acc = mfma4(a, make_float4((float)hv.x * sc, (float)hv.y * sc, (float)hv.z * sc, (float)hv.w * sc), acc);
+                    }
                     __builtin_amdgcn_wave_barrier();
                 }
             };
@@ -247,122 +235,104 @@ __global__ __launch_bounds__((CmGeo<LP, NQT>::WAVES * 64)) void cell_fwd_mfma_ke
 #pragma unroll
                 for (int kt = 0; kt < NKT; kt++)
                     if (kt < nkt) {
-#pragma unroll
-                        for (int qt = 0; qt < NQT; qt++) {
-                            const int j = j0 + 16 * kt + 4 * g;
-                            bstore_floats<4>(rs_p, tile_off(qt, j), lg[kt][qt], qok[qt] ? min(max(ct.nk - j, 0), 4) : 0);
-                        }
+                        const int j = j0 + 16 * kt + 4 * g;
+                        bstore_floats<4>(rs_p, row_off + j * 4, lg[kt], qok ? min(max(ct.nk - j, 0), 4) : 0);
                     }
             };
 
-            if (nch == 1) {
-                const int nkt = (ct.nk + 15) >> 4;
-                logits_chunk(0, nkt);
-#pragma unroll
-                for (int qt = 0; qt < NQT; qt++) {
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int kt = 0; kt < NKT; kt++)
-#pragma unroll
-                        for (int t = 0; t < 4; t++) mx = fmaxf(mx, lg[kt][qt][t]);
-                    mx = col_max(mx);
-                    mx = mx == -INFINITY ? 0.f : mx;  // (an unused query slot: every weight 0)
-                    float sum = 0.f;
-#pragma unroll
-                    for (int kt = 0; kt < NKT; kt++)
-#pragma unroll
-                        for (int t = 0; t < 4; t++) {
-                            lg[kt][qt][t] = __expf(lg[kt][qt][t] - mx);  // exp(-inf) = 0
-                            sum += lg[kt][qt][t];
-                        }
-                    sum = col_sum(sum);
-                    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-#pragma unroll
-                    for (int kt = 0; kt < NKT; kt++)
-#pragma unroll
-                        for (int t = 0; t < 4; t++) lg[kt][qt][t] *= inv;
-                }
-                store_tile_rows(0, nkt);
-                values_chunk(0, nkt);
-            } else {
+            // one pass over the chunks when the whole key list fits the registers (weights made in place), else two: logits parked
+            // in pbuf with a running max / sum, then the weights (one call site per sweep keeps the kernel inside the instruction cache)
+            const int npass = nch == 1 ? 1 : 2;
+#pragma unroll 1
+            for (int pass = 0; pass < npass; pass++) {
+                const float m_fin = run_m == -INFINITY ? 0.f : run_m;
+                const float inv_fin = run_l > 0.f ? 1.0f / run_l : 0.f;
+#pragma unroll 1
                 for (int ch = 0; ch < nch; ch++) {
                     const int j0 = ch * 16 * NKT, nkt = (min(16 * NKT, ct.nk - j0) + 15) >> 4;
-                    logits_chunk(j0, nkt);
-#pragma unroll
-                    for (int qt = 0; qt < NQT; qt++) {
+                    if (pass == 0) {
+                        logits_chunk(j0, nkt);
                         float mx = -INFINITY;
 #pragma unroll
                         for (int kt = 0; kt < NKT; kt++)
 #pragma unroll
-                            for (int t = 0; t < 4; t++) mx = fmaxf(mx, lg[kt][qt][t]);
+                            for (int t = 0; t < 4; t++) mx = fmaxf(mx, lg[kt][t]);
                         mx = col_max(mx);
-                        const float m_new = fmaxf(run_m[qt], mx);
-                        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+                        const float m_new = fmaxf(run_m, mx);
+                        const float m_use = m_new == -INFINITY ? 0.f : m_new;  // (an unused query slot: every weight 0)
                         float sum = 0.f;
+                        if (nch == 1) {
+#pragma unroll
+                            for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+                                for (int t = 0; t < 4; t++) {
+                                    lg[kt][t] = __expf(lg[kt][t] - m_use);  // exp(-inf) = 0
+                                    sum += lg[kt][t];
+                                }
+                            sum = col_sum(sum);
+                            const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+                            for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+                                for (int t = 0; t < 4; t++) lg[kt][t] *= inv;
+                        } else {
+#pragma unroll
+                            for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+                                for (int t = 0; t < 4; t++) sum += __expf(lg[kt][t] - m_use);
+                            sum = col_sum(sum);
+                            run_l = (run_m == -INFINITY ? 0.f : run_l * __expf(run_m - m_use)) + sum;
+                            run_m = m_new;
+                            store_tile_rows(j0, nkt);  // raw logits, parked (-inf where there is no pair)
+                            continue;
+                        }
+                    } else {
 #pragma unroll
                         for (int kt = 0; kt < NKT; kt++)
-#pragma unroll
-                            for (int t = 0; t < 4; t++) sum += __expf(lg[kt][qt][t] - m_use);
-                        sum = col_sum(sum);
-                        run_l[qt] = (run_m[qt] == -INFINITY ? 0.f : run_l[qt] * __expf(run_m[qt] - m_use)) + sum;
-                        run_m[qt] = m_new;
-                    }
-                    store_tile_rows(j0, nkt);  // raw logits, parked
-                }
-                for (int ch = 0; ch < nch; ch++) {
-                    const int j0 = ch * 16 * NKT, nkt = (min(16 * NKT, ct.nk - j0) + 15) >> 4;
-#pragma unroll
-                    for (int kt = 0; kt < NKT; kt++)
-                        if (kt < nkt) {
-#pragma unroll
-                            for (int qt = 0; qt < NQT; qt++) {
-                                bload_floats<4>(rs_p, tile_off(qt, j0 + 16 * kt + 4 * g), lg[kt][qt]);
-                                bload_words<4>(rs_rel, tile_off(qt, j0 + 16 * kt + 4 * g), w[kt][qt]);
-                            }
-                        }
-#pragma unroll
-                    for (int qt = 0; qt < NQT; qt++) {
-                        const float m_use = run_m[qt] == -INFINITY ? 0.f : run_m[qt];
-                        const float inv = run_l[qt] > 0.f ? 1.0f / run_l[qt] : 0.f;
+                            if (kt < nkt) bload_floats<4>(rs_p, row_off + (j0 + 16 * kt + 4 * g) * 4, lg[kt]);
 #pragma unroll
                         for (int kt = 0; kt < NKT; kt++)
 #pragma unroll
                             for (int t = 0; t < 4; t++) {
-                                const bool pair = kt < nkt && qok[qt] && j0 + 16 * kt + 4 * g + t < ct.nk && !(w[kt][qt][t] >> 31);
-                                lg[kt][qt][t] = pair ? __expf(lg[kt][qt][t] - m_use) * inv : 0.f;
+                                const bool in_row = kt < nkt && qok && j0 + 16 * kt + 4 * g + t < ct.nk;  // (parked -inf: exp = 0)
+                                lg[kt][t] = in_row ? __expf(lg[kt][t] - m_fin) * inv_fin : 0.f;
                             }
                     }
                     store_tile_rows(j0, nkt);
                     values_chunk(j0, nkt);
                 }
             }
-#pragma unroll
-            for (int qt = 0; qt < NQT; qt++)
-                if (qok[qt]) *reinterpret_cast<f32x4c *>(out + (size_t)qid[qt] * C + hoff) = acc[qt];  // features 4g .. 4g + 3 of query n
+            if (qok) *reinterpret_cast<f32x4c *>(out + (size_t)qid * C + hoff) = acc;  // features 4g .. 4g + 3 of query n
         }
     }
 }
 
-template <int LP, int NQT>
+template <int LP>
 static void launch_mfma_fwd(const pointops2_cell_plan *plan, int h, int L, const float *q, const float *k, const float *v, const float *table_q,
                             const float *table_k, const float *table_v, float *out, float *pbuf) {
-    using G = CmGeo<LP, NQT>;
+    using G = CmGeo<LP>;
     const size_t lds = G::lds_bytes();
-    allow_big_lds(cell_fwd_mfma_kernel<LP, NQT>, lds);
+    allow_big_lds(cell_fwd_mfma_kernel<LP>, lds);
     const dim3 grid(cell_grid_x(1, plan->n_cells, h, G::WAVES), h);
-    hipLaunchKernelGGL((cell_fwd_mfma_kernel<LP, NQT>), grid, dim3(G::WAVES * 64), lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out,
+    hipLaunchKernelGGL((cell_fwd_mfma_kernel<LP>), grid, dim3(G::WAVES * 64), lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out,
                        pbuf, (size_t)plan->n_pairs);
 }
 
 // fp32 operands, d = 16, L <= 80.  Returns false when the matrix-core forward does not apply (the caller then runs cell_attn.hip's).
 bool cell_fwd_mfma_launch(const pointops2_cell_plan *plan, int h, int L, const float *q, const float *k, const float *v, const float *table_q,
                           const float *table_k, const float *table_v, float *out, float *pbuf) {
-    static const bool enabled = getenv("P2_CELL_MFMA") == nullptr || atoi(getenv("P2_CELL_MFMA")) != 0;
-    if (!enabled || L > 80) return false;
-    // One query tile (16 queries) per pass over a piece's keys: with two, the logits and packed words of 2 x CM_NKT tiles do not fit
-    // the 256 registers of two waves per SIMD (458 spilled).  Pieces of more than 16 queries run as groups (KT recomputed per group).
-    if (L <= 64) launch_mfma_fwd<64, 1>(plan, h, L, q, k, v, table_q, table_k, table_v, out, pbuf);
-    else launch_mfma_fwd<80, 1>(plan, h, L, q, k, v, table_q, table_k, table_v, out, pbuf);
+    // P2_CELL_MFMA: 0 = never, 1 = always (when it applies), unset = where it was measured faster than cell_attn.hip's VALU forward
+    // (tools/bench_cell.py, MI355X, the four stages of the S3DIS scene, even / odd pattern, us MFMA : VALU): 292:321 / 372:300,
+    // 163:193 / 190:180, 114:152 / 117:120, 103:150 / 92:96.  The matrix-core tiles are 16 queries wide: the shifted pattern of the
+    // two large stages cuts the cloud into many cells of ~9 queries (n_pairs / n_keyslots), whose tiles stay half empty.
+    static const int mode = getenv("P2_CELL_MFMA") ? atoi(getenv("P2_CELL_MFMA")) : -1;
+    if (mode == 0 || L > 80) return false;
+    if (mode < 0) {
+        const double avg_queries = (double)plan->n_pairs / (double)(plan->n_keyslots > 0 ? plan->n_keyslots : 1);
+        if ((long long)plan->n_points * h >= 96000 && avg_queries < 15.0) return false;
+    }
+    if (L <= 64) launch_mfma_fwd<64>(plan, h, L, q, k, v, table_q, table_k, table_v, out, pbuf);
+    else launch_mfma_fwd<80>(plan, h, L, q, k, v, table_q, table_k, table_v, out, pbuf);
     return true;
 }
 

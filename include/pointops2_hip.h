@@ -40,6 +40,9 @@ void *pointops2_get_stream(void);
 const char *pointops2_last_error(void);
 /* library/ABI version, bumped when a signature changes */
 int pointops2_abi_version(void);
+/* Diagnostic: how long (ticks of the 100 MHz clock, default 2 s) a workgroup of the round sampler waits at its grid barrier before
+ * the sampler gives up and pointops2_last_error() reports the call's indices invalid (tests force the path with a tiny value). */
+void pointops2_diag_set_fps_patience(unsigned long long ticks_100mhz);
 
 /* ------------------------------------------------------------------------------------------ */
 /* PART 1 — the reference's launcher set                                                      */
@@ -292,6 +295,9 @@ typedef struct pointops2_cell_plan {
     int table_rows;          /* L the packed rel-pos indices of relp were clamped to (pass 2): the attention launchers */
                              /* reject tables with any other row count (ABI version 2) */
     int max_queries;         /* the max_queries the plan was cut with in pass 1 (0 = uncut): sizes the kernels' query tiles */
+    const int *task_list;    /* optional (NULL: all cells / the task_first, task_step share): the cell ids this launch works on, */
+    const int *task_count;   /* device [1]: how many of them.  One scene over several ranks with cells assigned by OWNER of */
+                             /* their first query (sharding.py, halo exchange): same zero-fill rules as a task_step share. */
 } pointops2_cell_plan;
 size_t pointops2_cell_plan_workspace_bytes(int N);
 void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_cluster, const int *s_starts, const int *l_cluster,

@@ -19,6 +19,7 @@ I, U, P, Z, F = ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t, c
 # name -> argtypes; mirrors include/pointops2_hip.h one to one
 SIGNATURES = {
     "pointops2_set_stream": [P],
+    "pointops2_diag_set_fps_patience": [ctypes.c_ulonglong],
     "pointops2_set_table_rows": [I],
     "pointops2_set_workspace": [P, Z],
     "pointops2_set_point_count": [I],

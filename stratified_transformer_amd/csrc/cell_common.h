@@ -127,7 +127,8 @@ struct CellTask {
 };
 // (everything about a cell is wave-uniform: held in scalar registers)
 __device__ __forceinline__ CellTask cell_task(const pointops2_cell_plan &pl, int task) {
-    const int cell = __builtin_amdgcn_readfirstlane(pl.cell_perm[task]);
+    // (an explicit task list holds cell ids; otherwise `task` is a position of the size-sorted cell list)
+    const int cell = __builtin_amdgcn_readfirstlane(pl.task_list != nullptr ? pl.task_list[task] : pl.cell_perm[task]);
     CellTask t;
     t.qs = __builtin_amdgcn_readfirstlane(pl.cell_qstart[cell]);
     t.nq = __builtin_amdgcn_readfirstlane(pl.cell_qstart[cell + 1]) - t.qs;
@@ -142,10 +143,12 @@ __device__ __forceinline__ int snake_task(int round, int slot, int slots) { retu
 // A launch may work on a share of the cells only (pointops2_cell_plan.task_first / task_step: one scene over several ranks):
 // the i-th task of the launch is cell_perm[first + i * step]
 __device__ __forceinline__ int share_count(const pointops2_cell_plan &pl, int n) {
+    if (pl.task_list != nullptr) return __builtin_amdgcn_readfirstlane(pl.task_count[0]);
     const int step = pl.task_step > 1 ? pl.task_step : 1, first = pl.task_step > 1 ? pl.task_first : 0;
     return n > first ? (n - first + step - 1) / step : 0;
 }
 __device__ __forceinline__ int share_task(const pointops2_cell_plan &pl, int i) {
+    if (pl.task_list != nullptr) return i;
     return pl.task_step > 1 ? pl.task_first + i * pl.task_step : i;
 }
 

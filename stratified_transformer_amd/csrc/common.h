@@ -41,6 +41,12 @@ bool knn_grid_launch(int m, int k, int n, int b, const float *xyz, const float *
 
 inline void set_error(const char *msg) { state().error = msg; }
 
+// A status word that kernels can set while they run (pinned host memory, mapped into every device): failures that only a running
+// kernel can detect - the round sampler's grid barrier giving up, fps_lazy.hip - reach the host without a synchronisation of their
+// own.  pointops2_last_error() reports a set word (and clears it) at the next library call after the kernel has run.
+unsigned *async_status_word();               // device-visible address (nullptr if the allocation failed)
+constexpr unsigned ASYNC_FPS_BARRIER_TIMEOUT = 1u;
+
 inline bool check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

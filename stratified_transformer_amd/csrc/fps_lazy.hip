@@ -70,12 +70,14 @@ __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, _
 // invalidate the whole L2 of the workgroup's XCD - sixteen workgroups on eight XCDs, every ~35 us - and the attention kernels
 // that run beside the sampler live on L2 hits: with release / acquire atomics here they took 1.6x (forward) to 2x (backward)
 // as long (tools/interference.py).
-// Safety net: a workgroup that has waited LZ_PATIENCE ticks of the 100 MHz clock (2 s: the whole kernel takes milliseconds)
+// Safety net: a workgroup that has waited `patience` ticks of the 100 MHz clock (2 s: the whole kernel takes milliseconds)
 // poisons the counter, which releases every waiter of the element, and all of them leave (returns false): a grid that cannot
-// make progress for a reason outside the algorithm must still drain.
+// make progress for a reason outside the algorithm (its workgroups not resident together: CUs held by other work) must still
+// drain.  The element's indices are then incomplete; the poisoning workgroup sets ASYNC_FPS_BARRIER_TIMEOUT in the library's
+// status word, which pointops2_last_error() turns into an error at the next library call after the kernel ran.
 constexpr unsigned LZ_POISON = 0x40000000u;
-constexpr unsigned long long LZ_PATIENCE = 200000000ull;
-__device__ __forceinline__ bool group_barrier(unsigned *bar, unsigned target, int G, int *s_flag) {
+extern unsigned long long g_fps_patience;  // misc.hip (pointops2_diag_set_fps_patience): LZ_PATIENCE in ticks, 2 s by default
+__device__ __forceinline__ bool group_barrier(unsigned *bar, unsigned target, int G, int *s_flag, unsigned long long patience, unsigned *status) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's device-scope stores have been performed
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -85,8 +87,10 @@ __device__ __forceinline__ bool group_barrier(unsigned *bar, unsigned target, in
             const unsigned long long t0 = wall_clock64();
             while ((v = __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
                 __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > LZ_PATIENCE) {
+                if (wall_clock64() - t0 > patience) {
                     __hip_atomic_fetch_add(bar, LZ_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the call's indices are incomplete from here on: say so where the host will see it (common.h, async_status_word)
+                    if (status != nullptr) __hip_atomic_store(status, ASYNC_FPS_BARRIER_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (a plain store: no PCIe atomics needed)
                     v = LZ_POISON;
                     break;
                 }
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
                                                          const unsigned *__restrict__ rank, const int *__restrict__ prev_idx,
                                                          const int *__restrict__ prev_offset, const int *__restrict__ verified,
                                                          int *__restrict__ idx, unsigned char *__restrict__ xchg_all,
+                                                         unsigned long long patience, unsigned *__restrict__ status,
                                                          unsigned long long *__restrict__ dbg = nullptr) {
     unsigned long long c_ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
     auto stamp = [&](int ph) {
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(LZ_NT) void fps_lazy_kernel(int Bref, int log2B, in
         }
         stamp(5);  // 5: gather
         round++;
-        if (!group_barrier(bar, round * (unsigned)G, G, &s_abort)) return;  // (uniform in the workgroup; see LZ_PATIENCE)
+        if (!group_barrier(bar, round * (unsigned)G, G, &s_abort, patience, status)) return;  // (uniform in the workgroup; see LZ_PATIENCE)
         stamp(10);  // 10: waiting for the other workgroups
         // ---- everybody reads everybody's list (in workgroup order, cut at CAP: what is cut is bounded by its workgroup's top).
         //      One trip: lane q of every wave fetches header q while the wave fetches - speculatively - entries of "its" workgroup ----
@@ -701,11 +706,11 @@ void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, co
         if (slots <= 8) {
             allow_big_lds(fps_lazy_kernel<true, 8>, lz_lds_bytes());
             hipLaunchKernelGGL((fps_lazy_kernel<true, 8>), dim3(G, b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, 0, xyz, offset, new_offset, pts, rank, prev_idx,
-                               prev_offset, verified, idx, (unsigned char *)xchg, dbg);
+                               prev_offset, verified, idx, (unsigned char *)xchg, g_fps_patience, async_status_word(), dbg);
         } else {
             allow_big_lds(fps_lazy_kernel<true, LZ_NSLOT>, lz_lds_bytes());
             hipLaunchKernelGGL((fps_lazy_kernel<true, LZ_NSLOT>), dim3(G, b), dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, 0, xyz, offset, new_offset, pts, rank, prev_idx,
-                               prev_offset, verified, idx, (unsigned char *)xchg, dbg);
+                               prev_offset, verified, idx, (unsigned char *)xchg, g_fps_patience, async_status_word(), dbg);
         }
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
@@ -729,11 +734,11 @@ void fps_lazy_launch(int b, int n_max, int Bref, int log2B, const float *xyz, co
         if (slots <= 8) {
             allow_big_lds(fps_lazy_kernel<false, 8>, lz_lds_bytes());
             hipLaunchKernelGGL((fps_lazy_kernel<false, 8>), grid, dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, c0, xyz, offset, new_offset, pts, rank, prev_idx,
-                               prev_offset, verified, idx, (unsigned char *)xchg, (unsigned long long *)nullptr);
+                               prev_offset, verified, idx, (unsigned char *)xchg, g_fps_patience, async_status_word(), (unsigned long long *)nullptr);
         } else {
             allow_big_lds(fps_lazy_kernel<false, LZ_NSLOT>, lz_lds_bytes());
             hipLaunchKernelGGL((fps_lazy_kernel<false, LZ_NSLOT>), grid, dim3(LZ_NT), lz_lds_bytes(), st, Bref, log2B, c0, xyz, offset, new_offset, pts, rank, prev_idx,
-                               prev_offset, verified, idx, (unsigned char *)xchg, (unsigned long long *)nullptr);
+                               prev_offset, verified, idx, (unsigned char *)xchg, g_fps_patience, async_status_word(), (unsigned long long *)nullptr);
         }
         held_cus_note(st, (int)(grid.x * grid.y));
     }

@@ -206,6 +206,23 @@ __global__ __launch_bounds__(1024) void diag_hold_kernel(int micros, int mode, u
 }
 }  // namespace p2
 
+namespace p2 {
+static unsigned *g_async_status = nullptr;
+unsigned long long g_fps_patience = 200000000ull;  // 2 s of the 100 MHz clock (fps_lazy.hip, LZ_PATIENCE)
+unsigned *async_status_word() {
+    static unsigned *dev_ptr = [] {
+        unsigned *host = nullptr;
+        void *dev = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&host), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return (unsigned *)nullptr;
+        *host = 0u;
+        if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) return (unsigned *)nullptr;
+        g_async_status = host;
+        return reinterpret_cast<unsigned *>(dev);
+    }();
+    return dev_ptr;
+}
+}  // namespace p2
+
 extern "C" {
 
 void pointops2_set_stream(void *hip_stream) { state().stream = reinterpret_cast<hipStream_t>(hip_stream); }
@@ -213,8 +230,18 @@ void *pointops2_get_stream(void) { return reinterpret_cast<void *>(state().strea
 const char *pointops2_last_error(void) {
     const char *e = state().error;
     state().error = nullptr;
+    if (e == nullptr) {
+        unsigned *w = g_async_status;  // (never allocates here)
+        if (w != nullptr) {
+            const unsigned bits = __atomic_exchange_n(w, 0u, __ATOMIC_RELAXED);
+            if (bits & ASYNC_FPS_BARRIER_TIMEOUT)
+                e = "furthestsampling: a workgroup of the round sampler waited for its grid barrier beyond its patience and the sampler "
+                    "gave up - the sample indices of that call are INVALID (fps_lazy.hip; P2_FPS_STEPWISE=1 selects the step-by-step sampler)";
+        }
+    }
     return e;
 }
+void pointops2_diag_set_fps_patience(unsigned long long ticks_100mhz) { g_fps_patience = ticks_100mhz; }
 int pointops2_abi_version(void) { return 2; }  // 2: pointops2_cell_plan.table_rows, pointops2_csr_matches_launcher
 void pointops2_set_table_rows(int L) { state().table_rows = L; }
 void pointops2_set_point_count(int N) { state().total_points = N; }

@@ -70,7 +70,9 @@ def data_prepare(coord, feat, label, split="train", voxel_size=0.04, voxel_max=N
         coord, feat, label = coord[crop], feat[crop], label[crop]
     coord = coord - coord.min(0)[0]
     feat = feat.float()
-    return coord.float(), feat / feat_div if feat_div else feat, label.long()
+    if feat_div:  # a true division, as torch's CPU kernels evaluate `FloatTensor / 255.` (:200): on the GPU `tensor / python scalar` multiplies
+        feat = torch.div(feat, torch.tensor(float(feat_div), dtype=torch.float32, device=feat.device))  # by the fp32 reciprocal instead
+    return coord.float(), feat, label.long()
 
 
 # ---- readers of the scene files the loaders open (nothing is executed from the file) ----

@@ -45,6 +45,9 @@ class BlockIndex:
     n_dense: torch.Tensor          # [N] i64 dense keys per query (diagnostics)
     cells: object = None           # CellPlan of the same pattern (stage_index_hip(..., cell_table_rows=L)), else None
     shard: object = None           # (QueryShard, bounds, (rank, world)) cached by pipeline.attention_block for a sharded scene
+    parts: object = None           # the stage's four window partitions (stage_index_hip): sharding by window ownership needs "large"
+    owner: object = None           # (owner_of, bounds, order) of the stage (sharding.window_owners), shared by both patterns
+    halo: object = None            # cached (HaloShard | (plan, HaloPlan), (rank, world, kind)) of this pattern
 
 
 def batch_ids(offset, n):
@@ -195,7 +198,8 @@ class CellPlanStruct(ctypes.Structure):
                 ("n_keyslots", ctypes.c_int), ("counts", ctypes.c_void_p), ("parent_first", ctypes.c_void_p), ("cell_perm", ctypes.c_void_p), ("cell_qstart", ctypes.c_void_p),
                 ("cell_kbase", ctypes.c_void_p), ("cell_pbase", ctypes.c_void_p), ("cell_order", ctypes.c_void_p),
                 ("qcell", ctypes.c_void_p), ("cell_keys", ctypes.c_void_p), ("kcell", ctypes.c_void_p), ("relp", ctypes.c_void_p),
-                ("task_first", ctypes.c_int), ("task_step", ctypes.c_int), ("table_rows", ctypes.c_int), ("max_queries", ctypes.c_int)]
+                ("task_first", ctypes.c_int), ("task_step", ctypes.c_int), ("table_rows", ctypes.c_int), ("max_queries", ctypes.c_int),
+                ("task_list", ctypes.c_void_p), ("task_count", ctypes.c_void_p)]
 
 
 @dataclass
@@ -223,6 +227,8 @@ class CellPlan:
     relp: torch.Tensor             # [P] i32 (bit pattern of the packed word)
     struct: CellPlanStruct = None
     max_queries: int = 0           # the cut of pass 1 (cell_max_queries; 0 = uncut cells)
+    task_list: torch.Tensor = None   # optional [<= n_cells] i32 cell ids + task_count [1] i32: an explicit share (with_tasks())
+    task_count: torch.Tensor = None
     task_first: int = 0            # this launch's share of the cells: cell_perm[task_first::task_step] (share(): one scene over ranks)
     task_step: int = 1
 
@@ -232,12 +238,19 @@ class CellPlan:
             self.struct = CellPlanStruct(self.n_points, self.n_cells, self.n_parents, self.n_pairs, self.n_keyslots, ptr(self.counts),
                                          ptr(self.parent_first), ptr(self.cell_perm), ptr(self.cell_qstart),
                                          ptr(self.cell_kbase), ptr(self.cell_pbase), ptr(self.cell_order), ptr(self.qcell), ptr(self.cell_keys),
-                                         ptr(self.kcell), ptr(self.relp), int(self.task_first), int(self.task_step), int(self.table_rows), int(self.max_queries))
+                                         ptr(self.kcell), ptr(self.relp), int(self.task_first), int(self.task_step), int(self.table_rows), int(self.max_queries),
+                                         ptr(self.task_list), ptr(self.task_count))
         return ctypes.byref(self.struct)
 
     @property
     def partial(self):
-        return self.task_step > 1
+        return self.task_step > 1 or self.task_list is not None
+
+    def with_tasks(self, task_list, task_count):
+        """The same plan restricted to the cells `task_list[:task_count[0]]` (cell ids, device tensors): sharding.py assigns cells
+        to the rank that owns their first query."""
+        import dataclasses
+        return dataclasses.replace(self, struct=None, task_first=0, task_step=1, task_list=task_list, task_count=task_count)
 
     def share(self, rank, world):
         """The same plan restricted to every world-th cell (by size order) starting at `rank`: the unit of sharding.sharded_cell_attention."""
@@ -342,7 +355,7 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
                          ptr(cells["cell_kbase"]), ptr(cells["cell_pbase"]), ptr(cell_keys), ptr(kcell), ptr(relp))
                     plan = CellPlan(N, n_cells, P, K, nk_max, int(cell_table_rows), n_parents, cell_keys=cell_keys, kcell=kcell, relp=relp,
                                     max_queries=int(cell_max_queries), **cells)
-                out[which] = BlockIndex(index_0, index_1, offsets, counts.max(), rel, None, plan)
+                out[which] = BlockIndex(index_0, index_1, offsets, counts.max(), rel, None, plan, parts=parts)
 
         for shifted, sname, lname in ((0, "small", "large"), (1, "small_shift", "large_shift")):
             if shifted not in patterns:

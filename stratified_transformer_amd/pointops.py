@@ -704,31 +704,54 @@ def Divide2Patch(nsample, xyz, offset, return_offset=False, anchor_scale=None):
     return (p_idx, new_offset) if return_offset else p_idx
 
 
+class _WeightedGather(Function):
+    """out[n, :] = sum_i weight[n, i] * input[idx[n, i], :], accumulated in the order i = 0 .. k-1 from zero (what the reference's torch
+    loop :767-769 computes, bit for bit) - by the interpolation kernels (interpolation_cuda_kernel.cu:5-33) instead of k gathers,
+    k multiplies and k adds over [n, c] temporaries."""
+
+    @staticmethod
+    def forward(ctx, input, idx, weight):
+        input, idx, weight = input.contiguous(), idx.contiguous(), weight.contiguous()
+        n, k = idx.shape
+        m, c = input.shape
+        output = _zeros((n, c), input)
+        pointops_cuda.interpolation_forward_cuda(n, c, k, input, idx, weight, output)
+        ctx.m = m
+        ctx.save_for_backward(input, idx, weight)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, idx, weight = ctx.saved_tensors
+        n, k = idx.shape
+        grad_output = grad_output.contiguous()
+        grad_input = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            grad_input = _zeros((ctx.m, grad_output.shape[1]), grad_output)
+            pointops_cuda.interpolation_backward_cuda(n, grad_output.shape[1], k, grad_output, idx, weight, grad_input)
+        if ctx.needs_input_grad[2]:  # (only interpolation_v2 with coordinates that require a gradient)
+            grad_weight = torch.stack([(grad_output * input[idx[:, i].long(), :]).sum(-1) for i in range(k)], 1)
+        return grad_input, None, grad_weight
+
+
+def _inverse_distance_weights(dist):
+    dist_recip = 1.0 / (dist + 1e-8)
+    return dist_recip / torch.sum(dist_recip, dim=1, keepdim=True)
+
+
 def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
-    """:756-770  inverse-distance weighted k-NN interpolation (differentiable w.r.t. feat via torch indexing)"""
+    """:756-770  inverse-distance weighted k-NN interpolation of feat (m, c) onto new_xyz (n, 3) -> (n, c); differentiable w.r.t. feat"""
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
     idx, dist = knnquery(k, xyz, new_xyz, offset, new_offset)
-    dist_recip = 1.0 / (dist + 1e-8)
-    norm = torch.sum(dist_recip, dim=1, keepdim=True)
-    weight = dist_recip / norm
-    new_feat = _zeros((new_xyz.shape[0], feat.shape[1]), feat)
-    for i in range(k):
-        new_feat += feat[idx[:, i].long(), :] * weight[:, i].unsqueeze(-1)
-    return new_feat
+    return _WeightedGather.apply(feat, idx, _inverse_distance_weights(dist))
 
 
 def interpolation_v2(xyz, new_xyz, feat, offset, new_offset, k=3):
-    """:773-797"""
+    """:773-797  the same with the distances recomputed by torch (differentiable w.r.t. the coordinates)"""
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
     idx, _ = knnquery(k, xyz, new_xyz, offset, new_offset)
     dist = torch.sqrt(((new_xyz.unsqueeze(1) - xyz[idx.long()]) ** 2).sum(-1) + 1e-8)
-    dist_recip = 1.0 / (dist + 1e-8)
-    norm = torch.sum(dist_recip, dim=1, keepdim=True)
-    weight = dist_recip / norm
-    new_feat = _zeros((new_xyz.shape[0], feat.shape[1]), feat)
-    for i in range(k):
-        new_feat += feat[idx[:, i].long(), :] * weight[:, i].unsqueeze(-1)
-    return new_feat
+    return _WeightedGather.apply(feat, idx, _inverse_distance_weights(dist))
 
 
 class Interpolation(Function):

@@ -117,3 +117,40 @@ def test_config4_scannet_200k_properties():
                                   ("q", "k", "v", "table_q", "table_k", "table_v")):
             scale = max(1.0, float(g_ops.abs().max())) if name.startswith("table") else 1.0
             torch.testing.assert_close(t.grad / scale, g_ops / scale, rtol=5e-4, atol=5e-4, msg=lambda m, s=si, n=name: f"stage {s} grad {n}: {m}")
+
+
+def test_halo_of_eight_ranks_at_100k_points():
+    """with ownership by large window, what a rank has to receive per block and row tensor (its halo) stays below
+    25 % of what the all-gather variant delivers to it (all foreign rows), for 8 ranks on the 100 000-point scene, both patterns of
+    every stage, for the operators' shards and for the cell kernels' (which also move q and out rows of boundary cells).  The halo
+    lists are derived from the replicated index, so one process evaluates all eight ranks; the two ends of every transfer agree."""
+    from stratified_transformer_amd import pipeline, scene, sharding
+    cfg = pipeline.s3dis_config()
+    xyz = scene.make_room(100_000, seed=0)
+    states, results = pipeline.scene_pass(dev(xyz), dev(np.array([100_000], np.int32)), cfg, seed=1, cells=True)
+    torch.cuda.synchronize()
+    world = 8
+    worst = {}
+    for r in results[:3]:   # (stage 3 has 1 563 points: 195 per rank, all boundary)
+        owner = sharding.window_owners(r["even"].parts["large"], [r["even"].offsets, r["odd"].offsets], world)
+        owner_of, bounds, order = owner
+        sizes = np.diff(bounds)
+        assert sizes.min() > 0 and sizes.sum() == r["n"]
+        pairs = {}
+        for pname in ("even", "odd"):
+            blk = r[pname]
+            plans = [sharding.make_halo_shard(blk, owner_of, order, bounds, rk, world).halo for rk in range(world)]
+            cells = [sharding.make_halo_cells(blk.cells, owner_of, order, bounds, rk, world) for rk in range(world)]
+            for rk in range(world):
+                for other in range(world):   # what rk receives from `other` is what `other` sends to rk
+                    assert plans[rk].recv_splits[other] == plans[other].send_splits[rk]
+                    assert cells[rk][1].recv_splits[other] == cells[other][1].send_splits[rk]
+            assert sum(int(c[0].task_count[0]) for c in cells) == blk.cells.n_cells              # every cell has exactly one owner
+            pairs[pname] = [int(sharding.make_halo_shard(blk, owner_of, order, bounds, rk, world).index_1.shape[0]) for rk in range(world)]
+            worst[(r["stage"], pname)] = (max(p.halo_fraction() for p in plans), max(c[1].halo_fraction() for c in cells))
+        both = np.array(pairs["even"]) + np.array(pairs["odd"])
+        assert both.max() < 1.15 * both.mean(), both                                                # the stage's pairs are balanced over the ranks
+    for key, (ops_frac, cell_frac) in worst.items():
+        if key[0] <= 1:
+            assert ops_frac < 0.25 and cell_frac < 0.25, worst
+    print("halo fractions (operators, cells) per (stage, pattern):", {k: (round(a, 3), round(b, 3)) for k, (a, b) in worst.items()})

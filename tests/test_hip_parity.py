@@ -426,6 +426,16 @@ def test_grouping_and_interpolation(P):
     g2 = rng.standard_normal(want.shape, dtype=np.float32)
     got2.backward(dev(g2))
     np.testing.assert_allclose(_np(fs2.grad), ref.interpolation_backward(g2, i3, wgt, 750), rtol=1e-4, atol=1e-4)
+    # `interpolation` (the form Upsample calls) runs on the same kernels: the torch loop's sum order, and its gradient w.r.t. feat
+    assert torch.equal(got, got2)
+    got.backward(dev(g2))
+    np.testing.assert_allclose(_np(fs.grad), ref.interpolation_backward(g2, i3, wgt, 750), rtol=1e-4, atol=1e-4)
+    fs3 = _leaf(feat_s)
+    got3 = P.interpolation_v2(dev(new_xyz), dev(xyz), fs3, dev(noff), dev(off))
+    d_v2 = np.sqrt(((xyz[:, None, :] - new_xyz[i3]) ** 2).sum(-1) + np.float32(1e-8))     # :781: its own distances (sqrt(d^2 + 1e-8))
+    w_v2 = 1.0 / (d_v2 + np.float32(1e-8))
+    w_v2 = (w_v2 / w_v2.sum(1, keepdims=True)).astype(np.float32)
+    np.testing.assert_allclose(_np(got3), ref.interpolation_forward(feat_s, i3, w_v2), rtol=1e-4, atol=1e-4)
 
 
 def test_scatter_softmax_shim_on_gpu(P, golden):
@@ -1451,3 +1461,26 @@ def test_operators_reject_a_pair_list_of_another_cloud(P, golden):
     with pytest.raises(ValueError, match="pair list"):
         fused.window_attention(q, k, v, tq, tk, tv, offs, i1, rel)
     torch.cuda.synchronize()
+
+
+def test_fps_round_sampler_reports_a_barrier_timeout(P):
+    """when a workgroup of the round sampler gives up at its grid barrier (its partners not resident: CUs held by other
+    work), the element's indices are incomplete - that must not be silent.  The patience is forced to zero here: the kernel
+    drains, and the NEXT library call after it ran raises; with the patience restored the same call equals the oracle again."""
+    from stratified_transformer_amd import _lib
+    rng = np.random.default_rng(31)
+    xyz = rng.random((20000, 3), dtype=np.float32)
+    x, off, n_off = dev(xyz), dev(np.array([20000], np.int32)), dev(np.array([5001], np.int32))
+    lib = _lib.lib()
+    P.clear_caches()
+    try:
+        lib.pointops2_diag_set_fps_patience(0)
+        P.furthestsampling(x, off, n_off)          # several workgroups per cloud (20000 points): the first waiter gives up at once
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="grid barrier"):
+            P.csr_matches(dev(np.array([0, 1], np.int32)), dev(np.array([0], np.int32)))   # any library call surfaces it
+    finally:
+        lib.pointops2_diag_set_fps_patience(200000000)
+        P.clear_caches()
+    got = _np(P.furthestsampling(x, off, n_off))
+    assert np.array_equal(got, ref.furthestsampling(xyz, np.array([20000], np.int32), np.array([5001], np.int32)))

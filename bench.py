@@ -115,7 +115,8 @@ def run_gpu(args, rank, world):
     dev = torch.device("cuda", local % max(ndev, 1))
     torch.cuda.set_device(dev)
     cfg = pipeline.s3dis_config()
-    shard = (rank, world) if (args.shard and world > 1) else None
+    # --shard: ONE scene over the ranks; ownership by window with halo exchange (sharding.py) unless --shard-mode range
+    shard = ((rank, world, "halo") if args.shard_mode == "halo" else (rank, world)) if (args.shard and world > 1) else None
     xyz_np = scene.make_room(N_POINTS, seed=0 if shard else rank)
     xyz = torch.from_numpy(xyz_np).to(dev)
     offset = torch.tensor([N_POINTS], dtype=torch.int32, device=dev)
@@ -151,7 +152,10 @@ def run_gpu(args, rank, world):
         st, res = states, None
         for _ in range(max(args.warmup, 1)):
             st, res = pipeline.scene_pass(xyz, offset, cfg, st, fused=fused, shard=shard)
-        live = pipeline.Timer(True, only=("attn", "fps/", "comm/"))
+        live = pipeline.Timer(True, only=("attn", "fps/", "comm/") + (("index/",) if shard else ()))
+        if shard:
+            from stratified_transformer_amd import sharding
+            sharding.reset_bytes()
         barrier()
         with no_gc():
             t0 = time.perf_counter()
@@ -160,7 +164,11 @@ def run_gpu(args, rank, world):
             barrier()
             elapsed = max_over_ranks(time.perf_counter() - t0)
         states = st
-        return dict(elapsed=elapsed, live=live, results=summary(res))
+        leg = dict(elapsed=elapsed, live=live, results=summary(res))
+        if shard:
+            leg["bytes_moved"] = sharding.BYTES_MOVED
+            leg["halo_fraction"] = [r.get("halo_fraction") for r in res]
+        return leg
 
     del results
     out["single_ops"] = single_pass_leg(False)
@@ -468,6 +476,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=IN_FLIGHT_DEFAULT, help="batches in flight of the in_flight leg (fixed; 1 = skip the leg)")
     ap.add_argument("--shard", action="store_true", help="N > 1: ONE scene sharded over the ranks (SURVEY 8e) instead of one scene per rank")
+    ap.add_argument("--shard-mode", choices=("halo", "range"), default="halo",
+                    help="halo: rows owned by large window, only boundary rows travel; range: contiguous index ranges, all-gather of every row")
     args = ap.parse_args()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -545,6 +555,13 @@ def main():
         if sharded:
             live = component_table(run["single_cell"]["live"], K)
             line["collective_ms"] = round(sum(v["ms_per_step"] for k, v in live.items() if k.startswith("comm/")), 3)
+            # what does NOT shrink with the rank count (every rank samples and builds the whole index) and what travels: the
+            # Amdahl bound of the strong-scaling leg is in the line.  UNMEASURED on multi-GPU hardware from the build container.
+            line["replicated_ms"] = round(sum(v["ms_per_step"] for k, v in live.items() if k.startswith(("fps/", "index/"))), 3)
+            line["collective_bytes_per_step"] = {"cell": int(run["single_cell"].get("bytes_moved", 0) // K),
+                                                 "operator_api": int(run["single_ops"].get("bytes_moved", 0) // K)}
+            line["shard_mode"] = args.shard_mode
+            line["halo_fraction_per_stage_even_odd"] = run["single_cell"].get("halo_fraction")
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(run)
             line["cpu_baseline"] = base

@@ -23,7 +23,7 @@ def group_of(name):
         return "fps"
     if name.startswith("knn_"):
         return "knn"
-    if name.startswith("cell_fwd_kernel"):
+    if name.startswith("cell_fwd_kernel") or name.startswith("cell_fwd_mfma_kernel"):
         return "cell_attn_fwd"
     if name.startswith("cell_bwd_kernel") or name.startswith("cell_table_grad"):
         return "cell_attn_bwd"
@@ -45,7 +45,7 @@ def launches(prefix):
 # passes of each kind in the profiled process: the operator path launches a1_fwd once per block, the cell module cell_fwd_kernel;
 # every pass of either kind launches the grid kNN six times
 ops_passes = max(1, launches("a1_fwd_kernel") // blocks_per_pass)
-cell_passes = max(1, launches("cell_fwd_kernel") // blocks_per_pass)
+cell_passes = max(1, (launches("cell_fwd_kernel") + launches("cell_fwd_mfma_kernel")) // blocks_per_pass)
 all_passes = max(1, (launches("knn_grid_kernel") + launches("knn_lanes_kernel")) // 6)
 steps = all_passes
 # (the bench also runs forward-only passes: the backward group is normalised by the passes that HAVE a backward)

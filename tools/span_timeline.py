@@ -21,7 +21,8 @@ h1 = time.perf_counter()
 end = torch.cuda.Event(enable_timing=True)
 end.record()
 torch.cuda.synchronize()
-print('pass %.2f ms (host enqueue %.2f ms)' % (ref.elapsed_time(end), (h1 - h0) * 1e3))
+h2 = time.perf_counter()
+print('pass %.2f ms by events (host enqueue %.2f ms, host wall incl. the final synchronize %.2f ms)' % (ref.elapsed_time(end), (h1 - h0) * 1e3, (h2 - h0) * 1e3))
 rows = [(ref.elapsed_time(e0), ref.elapsed_time(e1), name) for name, e0, e1, _ in timer.spans]
 rows.sort()
 cur = None

@@ -313,7 +313,8 @@ static void launch_mfma_fwd(const pointops2_cell_plan *plan, int h, int L, const
     using G = CmGeo<LP>;
     const size_t lds = G::lds_bytes();
     allow_big_lds(cell_fwd_mfma_kernel<LP>, lds);
-    const dim3 grid(cell_grid_x(1, plan->n_cells, h, G::WAVES), h);
+    static const int cf_div = getenv("P2_CF_DIV") ? atoi(getenv("P2_CF_DIV")) : 1;
+    const dim3 grid(std::max(1, cell_grid_x(1, plan->n_cells, h, G::WAVES) / cf_div), h);
     hipLaunchKernelGGL((cell_fwd_mfma_kernel<LP>), grid, dim3(G::WAVES * 64), lds, state().stream, *plan, h, L, q, k, v, table_q, table_k, table_v, out,
                        pbuf, (size_t)plan->n_pairs);
 }

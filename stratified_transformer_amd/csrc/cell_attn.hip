@@ -571,7 +571,10 @@ __device__ __forceinline__ CFixScale c_row_scale(unsigned maxbits, int n) {
     return sc;
 }
 
-constexpr int CT_WAVES = 12;
+#ifndef CT_WAVES_OVERRIDE
+#define CT_WAVES_OVERRIDE 8  // (12 in round 2; with the grid below 8 measured 5 % less backward time per step: tools/bench_cell.py, round 3)
+#endif
+constexpr int CT_WAVES = CT_WAVES_OVERRIDE;
 
 template <int TA>
 struct CellTableGeo {
@@ -817,7 +820,7 @@ static void launch_cell_bwd(const pointops2_cell_plan *plan, int h, int hdim, in
                        dim3(CA_WAVES_BWD * 64), lds, st, *plan, h, L, grad_out, q, k, v, out, table_q, table_k, table_v, pbuf, gsbuf, plane, grad_q,
                        grad_k, grad_v);
     // the three table gradients read p / gs only
-    // Grid of the table-gradient bodies: ONE workgroup per free CU and body (round 2 used two), half of that on the three smaller stages.
+    // Grid of the table-gradient bodies: ONE workgroup of 8 waves per free CU and body (round 2: two of 12).
     // Measured (tools/bench_cell.py, backward of a block, us, two -> one -> half): stage 0 784 -> 717 -> 725 / 905 -> 831 -> 833 (plain / shifted
     // pattern), stage 1 512 -> 448 -> 433 / 505 -> 452 -> 423, stage 2 381 -> 345 -> 304 / 361 -> 302 -> 292, stage 3 317 -> 301 -> 303 /
     // 265 -> 223 -> 212: every workgroup pays a fixed zero-fill, a 12-round reduction through LDS and a 3 072-float atomic flush per body, and
@@ -825,7 +828,7 @@ static void launch_cell_bwd(const pointops2_cell_plan *plan, int h, int hdim, in
     // costs 40-70 %: those are bound by resident waves.)  P2_CT_PER_CU / P2_CT_DIV override.
     static const int ct_per_cu = getenv("P2_CT_PER_CU") ? atoi(getenv("P2_CT_PER_CU")) : 1;
     static const int ct_div_env = getenv("P2_CT_DIV") ? atoi(getenv("P2_CT_DIV")) : 0;
-    const int ct_div = ct_div_env > 0 ? ct_div_env : ((long long)plan->n_points * h >= 250000 ? 1 : 2);
+    const int ct_div = ct_div_env > 0 ? ct_div_env : 1;  // (with 12 waves per workgroup, halving the grid on the smaller stages paid; with 8 it does not)
     const int gx_t = std::max(1, cell_grid_x(ct_per_cu, plan->n_cells, h, CT_WAVES) / ct_div);
     const dim3 tgrid(gx_t, h), tblock(CT_WAVES * 64);
     // one grid for the three (P2_CELL_TABLE3=0: three launches in a row): backward of a block 10-120 us shorter, most on the small stages

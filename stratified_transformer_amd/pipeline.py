@@ -317,6 +317,24 @@ class _IndexBuilder:
             raise self._error
 
 
+_RETIRED = {}  # (device index, lane) -> deque of (event on the lane's main stream at the end of a pass, tensors kept alive until then)
+
+
+def _reap(device, lane):
+    import collections
+    q = _RETIRED.setdefault((torch.device(device).index, lane), collections.deque())
+    while q and (q[0][0].query() or len(q) > 4):
+        if not q[0][0].query():
+            q[0][0].synchronize()
+        q.popleft()
+
+
+def _retire(device, lane, main, keep):
+    ev = torch.cuda.Event()
+    ev.record(main)
+    _RETIRED[(torch.device(device).index, lane)].append((ev, keep))
+
+
 def _block_tensors(blk):
     """Every device tensor of a block pattern that the attention kernels read: allocated on the index stream, consumed on the main
     stream - all of them are recorded there (the pair list AND the cell plan: relp, cell_keys, ... - the caching allocator must not
@@ -356,6 +374,13 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     write, so the device may run them side by side (passes_in_flight): the sampling chain of the next batch - one
     CU wide, and a function of the coordinates alone - then runs beside the attention blocks of this one."""
     timer = timer or Timer(False)
+    # Tensors that are allocated under one stream and read by kernels of another (index tensors and cell plans: index stream ->
+    # main; samples, clouds, offsets: geometry / upload streams -> the others) are kept alive in `keep` until an event recorded
+    # at the END of the pass on the main stream has completed (_retire), instead of Tensor.record_stream(): that makes the
+    # allocator record one event per tensor and stream when the tensor is freed - ~200 markers at the end of a pass, 0.6-0.7 ms
+    # of the main stream between two passes (tools/span_timeline.py, round 3).
+    keep = []
+    _reap(xyz.device, lane)
     # nothing is carried over from an earlier pass: the CSC transpositions and the FPS sampler state are
     # rebuilt inside every pass (they are reused only WITHIN a pass, between blocks / the two FPS calls of a stage)
     P.clear_caches()
@@ -417,8 +442,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     if overlap:
         for s_ in (geo, knn_s, main):
             s_.wait_stream(up_s)
-            for t in plan_dev[1:] + strat_dev:
-                t.record_stream(s_)
+            keep.extend(plan_dev[1:] + strat_dev)
     level = [0]
 
     def transition(x, off, off_host):
@@ -432,8 +456,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         cloud_ready[level[0]] = ready
         if overlap:  # the grouping query leaves the sampling chain here
             knn_s.wait_stream(geo)
-            for t in (x, n_xyz, off, n_offset):
-                t.record_stream(knn_s)
+            keep.extend((x, n_xyz, off, n_offset))
         with torch.cuda.stream(knn_s):
             knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, x, n_xyz, off, n_offset)
         return n_xyz, n_offset, n_off_host, knn_idx
@@ -471,8 +494,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         ds, ev_ds, _ = geo_out[si]
         st = cfg.stages[si]
         if overlap:
-            for t in (ds, x, off):
-                t.record_stream(idx_s)
+            keep.extend((ds, x, off))
         with torch.cuda.stream(idx_s):
             parts_ctx = None
             if use_hip_index:
@@ -526,9 +548,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         ev.record(torch.cuda.current_stream(dev))  # (the index stream)
         with torch.cuda.stream(main):
             main.wait_event(ev)
-            for t in (x, off, ds) + _block_tensors(even_blk):
-                if torch.is_tensor(t):
-                    t.record_stream(main)
+            keep.extend(t for t in (x, off, ds) + _block_tensors(even_blk) if torch.is_tensor(t))
             if make:
                 states.append(make_stage_state(x, off, st, seed + si))
             state = states[si - first]
@@ -554,9 +574,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         ds, _, knn_idx = geo_out[si]
         if overlap:
             main.wait_event(ev_idx)
-            for t in (x, off, ds) + _block_tensors(even) + _block_tensors(odd):
-                if torch.is_tensor(t):
-                    t.record_stream(main)
+            keep.extend(t for t in (x, off, ds) + _block_tensors(even) + _block_tensors(odd) if torch.is_tensor(t))
         if make and si not in started:
             states.append(make_stage_state(x, off, st, seed + si))
         state = states[si - first]
@@ -603,6 +621,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         main.wait_stream(knn_s)
         main.wait_stream(idx_s)
     timer.run("mark/streams_joined", lambda: None)
+    _retire(dev, lane, main, keep)
     return states, results
 
 

@@ -18,9 +18,14 @@ import time
 h0 = time.perf_counter()
 pipeline.scene_pass(xyz, off, cfg, states, timer, fused=FUSED)
 h1 = time.perf_counter()
+timer.run("mark/tool_after_pass", lambda: None)
+torch.cuda.current_stream().synchronize()
+h1b = time.perf_counter()
+timer.run("mark/tool_after_stream_sync", lambda: None)
 end = torch.cuda.Event(enable_timing=True)
 end.record()
 torch.cuda.synchronize()
+print("host: pass returned at %.2f ms, main stream drained at %.2f ms" % ((h1 - h0) * 1e3, (h1b - h0) * 1e3))
 h2 = time.perf_counter()
 print('pass %.2f ms by events (host enqueue %.2f ms, host wall incl. the final synchronize %.2f ms)' % (ref.elapsed_time(end), (h1 - h0) * 1e3, (h2 - h0) * 1e3))
 rows = [(ref.elapsed_time(e0), ref.elapsed_time(e1), name) for name, e0, e1, _ in timer.spans]

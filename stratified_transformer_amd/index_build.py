@@ -48,6 +48,7 @@ class BlockIndex:
     parts: object = None           # the stage's four window partitions (stage_index_hip): sharding by window ownership needs "large"
     owner: object = None           # (owner_of, bounds, order) of the stage (sharding.window_owners), shared by both patterns
     halo: object = None            # cached (HaloShard | (plan, HaloPlan), (rank, world, kind)) of this pattern
+    cells_ready: object = None     # event on the build's stream: the cell plan is complete (the pair-list tensors may still be in flight)
 
 
 def batch_ids(offset, n):
@@ -338,11 +339,12 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
             else:
                 flat = torch.cat([torch.cat([p[5][N:N + 1], p[6]["counts"]]) for p in pend]).tolist()
                 totals = [(flat[9 * i], flat[9 * i + 1:9 * i + 6]) for i in range(len(pend))]
+            # The cell plans first: the window-centric kernels need nothing else of a pattern, so a caller that waits for `cells_ready`
+            # (pipeline.scene_pass) starts its attention blocks while the pair lists - 100 us per pattern at stage 0 - are still being written.
+            fills = []
             for (s, lg, ls, ls_starts, wc, offsets, cells, which), (M, ccounts) in zip(pend, totals):
                 index_0, index_1 = torch.empty(M, **i32), torch.empty(M, **i32)
                 rel = torch.empty((M, 3), **i32)
-                call("pointops2_pairs_fill_launcher", N, ptr(xyz), float(w32), _f32(quant_size), ptr(s.cluster), ptr(s.order), ptr(s.starts),
-                     ptr(lg.cluster), ptr(ls), ptr(ls_starts), ptr(wc), ptr(offsets), ptr(index_0), ptr(index_1), ptr(rel))
                 counts = offsets[1:] - offsets[:-1]
                 plan = None
                 if cells is not None:
@@ -356,6 +358,15 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
                     plan = CellPlan(N, n_cells, P, K, nk_max, int(cell_table_rows), n_parents, cell_keys=cell_keys, kcell=kcell, relp=relp,
                                     max_queries=int(cell_max_queries), **cells)
                 out[which] = BlockIndex(index_0, index_1, offsets, counts.max(), rel, None, plan, parts=parts)
+                fills.append((s, lg, ls, ls_starts, wc, offsets, index_0, index_1, rel))
+            if cell_table_rows is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                for (_, _, _, _, _, _, _, which), _t in zip(pend, totals):
+                    out[which].cells_ready = ev
+            for s, lg, ls, ls_starts, wc, offsets, index_0, index_1, rel in fills:
+                call("pointops2_pairs_fill_launcher", N, ptr(xyz), float(w32), _f32(quant_size), ptr(s.cluster), ptr(s.order), ptr(s.starts),
+                     ptr(lg.cluster), ptr(ls), ptr(ls_starts), ptr(wc), ptr(offsets), ptr(index_0), ptr(index_1), ptr(rel))
 
         for shifted, sname, lname in ((0, "small", "large"), (1, "small_shift", "large_shift")):
             if shifted not in patterns:

@@ -544,8 +544,12 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         st = cfg.stages[si]
         x, off, _ = clouds[si]
         ds = geo_out[si][0]
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))  # (the index stream)
+        cells_only = str(fused).startswith("cell") and shard is None and even_blk.cells_ready is not None
+        if cells_only:  # the window-centric kernels need the plan alone: they do not wait for the pair-list tensors
+            ev = even_blk.cells_ready
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))  # (the index stream)
         with torch.cuda.stream(main):
             main.wait_event(ev)
             keep.extend(t for t in (x, off, ds) + _block_tensors(even_blk) if torch.is_tensor(t))
@@ -573,7 +577,8 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
             odd.owner = even.owner   # one ownership per stage: the rows do not move between the blocks
         ds, _, knn_idx = geo_out[si]
         if overlap:
-            main.wait_event(ev_idx)
+            cells_only = str(fused).startswith("cell") and shard is None and odd is not None and odd.cells_ready is not None
+            main.wait_event(odd.cells_ready if cells_only else ev_idx)  # (same stream: the shifted pattern's plan is the later one)
             keep.extend(t for t in (x, off, ds) + _block_tensors(even) + _block_tensors(odd) if torch.is_tensor(t))
         if make and si not in started:
             states.append(make_stage_state(x, off, st, seed + si))

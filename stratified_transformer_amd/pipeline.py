@@ -589,7 +589,13 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         # behind ALL blocks of the first stage (its samples only arrive when the stage-0 sampler is through),
         # behind the FIRST block of a later stage (its samples are long there, and the late stages' blocks are
         # short enough for the launches to fall behind otherwise)
+        # (a two-block stage enqueues both blocks first: the host would otherwise sit in the next stage's index syncs while the device
+        #  has nothing of this stage left - a 0.4 ms hole between the two blocks of stage 1, tools/span_timeline.py)
         early = si + 1 in stages and si > first
+        # A pass on its own: behind block min(depth - 1, 3), so that the device has blocks queued while the host sits in the syncs (issued
+        # behind block 0, the host left a 0.3-0.4 ms hole in stages 1 and 2, tools/span_timeline.py).  Batches in flight keep round 2's
+        # order (behind block 0): there the host is the limit and the later position measured 11.0 -> 15.5 ms per batch.
+        early_after = 0 if inputs_resident else min(st.depth - 1, 3)
         for b in range(st.depth):
             if b == 0 and si in started:
                 continue
@@ -603,7 +609,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
             timer.stage = si
             out = attention_block(state, blk_b, timer, fused, shard)
             timer.stage = None
-            if early and b == 0 and builder is None:
+            if early and b == early_after and builder is None:
                 index(si + 1)
         results.append(dict(stage=si, n=x.shape[0], M_even=int(even.index_1.shape[0]), M_odd=int(odd.index_1.shape[0]),
                             even=even, odd=odd, downsample_idx=ds, out=out))

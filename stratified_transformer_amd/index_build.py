@@ -268,7 +268,8 @@ def cell_query_cap(n_points, heads):
     # measured on the four stages of the S3DIS configuration (points x heads = 300k, 150k, 75k, 37k; tools/bench_cell.py): pieces of 32
     # queries for the two large ones, 16 for the two small ones (8 / 4 there cost 5-25 % of the backward: every piece flushes its
     # keys' gradients; 32 there leaves too few pieces for the chip)
-    return 32 if n_points * heads >= 96000 else 16
+    big, small = int(os.environ.get("P2_CELL_CAP_BIG", 32)), int(os.environ.get("P2_CELL_CAP_SMALL", 16))   # (experiment knobs)
+    return big if n_points * heads >= 96000 else small
 
 
 def stage_partitions_hip(xyz, offset, window_size):

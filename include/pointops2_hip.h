@@ -221,6 +221,14 @@ size_t pointops2_index_workspace_bytes(int N);
 void pointops2_window_partition_launcher(int N, int b, const float *xyz, const int *offset, const float *bbox6, float size,
                                          float shift, int key_bits, int *cluster, int *order, int *starts, int *n_windows,
                                          void *ws, size_t ws_bytes);
+/* the four partitions of a stage in one sort (variant 0 small, 1 small shifted by window/2, 2 large = 2 window, 3 large shifted by
+ * window): cluster / order [4][N], starts [4][N+2], n_windows [4], same contents as four partition calls.  The key is of fixed width
+ * (ten bits per voxel coordinate: no bounding-box read-back); *overflow = 1 when a coordinate does not fit - the outputs are then
+ * meaningless (but in range) and the caller builds the partitions one by one. */
+size_t pointops2_partitions4_workspace_bytes(int N);
+void pointops2_window_partitions4_launcher(int N, int b, const float *xyz, const int *offset, const float *bbox6, float window,
+                                           int *cluster, int *order, int *starts, int *n_windows, int *overflow, void *ws,
+                                           size_t ws_bytes);
 void pointops2_window_coord_launcher(int N, const float *xyz, const float *bbox6, float window, int shifted, float *wc);
 void pointops2_sampled_buckets_launcher(int N, int m, const int *sample_idx, const int *l_order, const int *l_starts,
                                         const int *l_n_windows, int *sampled, int *ls, int *ls_starts, void *ws, size_t ws_bytes);

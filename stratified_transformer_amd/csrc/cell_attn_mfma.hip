@@ -148,9 +148,7 @@ __global__ __launch_bounds__((CmGeo<LP>::WAVES * 64)) void cell_fwd_mfma_kernel(
                             for (int t = 0; t < 4; t++) w[t] = w_nx[t];
                             {   // the next step's inputs: the next key tile of this axis, or the first one of the next axis
                                 const int kn = kt + 1 < nkt ? kt + 1 : 0;
-                                int key_n = keyid[0];
-#pragma unroll
-                                for (int u = 1; u < NKT; u++) key_n = kn == u ? keyid[u] : key_n;
+                                const int key_n = kt + 1 < nkt ? keyid[kt + 1 < NKT ? kt + 1 : 0] : keyid[0];
                                 kf_nx = ldg4(k + (size_t)key_n * C + hoff);
                                 bload_words<4>(rs_rel, row_off + (j0 + 16 * kn + 4 * g) * 4, w_nx);
                             }

@@ -95,6 +95,49 @@ __global__ void voxel_key_kernel(int N, int b, const float *__restrict__ xyz, co
     vals[i] = i;
 }
 
+// The four partitions of a stage (small / small shifted / large / large shifted windows: grid_sample x 4, :277,280,297,300) as ONE
+// sort: key = variant | batch | z | y | x with ten bits per coordinate - the reference's voxel id x + y mx + z mx my + batch mx my mz
+// orders the voxels of a variant the same way (every coordinate is below its multiplier), so the dense ranks are the same, and the
+// key width no longer depends on the bounding box (no host read-back before the sort).  A coordinate that needs more than ten bits
+// sets *overflow: the caller reads it with its next read-back and builds the partitions one by one instead.
+__global__ void voxel_key4_kernel(int N, int b, const float *__restrict__ xyz, const int *__restrict__ offset, const float *__restrict__ bbox6,
+                                  float window, int batch_bits, unsigned long long *__restrict__ keys, int *__restrict__ vals,
+                                  int *__restrict__ overflow) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4 * N) return;
+    const int v = t / N, i = t - v * N;
+    const float size = v < 2 ? window : __fmul_rn(2.f, window);
+    const float shift = v == 1 ? __fmul_rn(0.5f, window) : (v == 3 ? window : 0.f);
+    int bid = 0;
+    while (bid < b - 1 && i >= offset[bid]) bid++;
+    unsigned long long key = (unsigned long long)((v << batch_bits) + bid) << 30;
+    bool bad = false;
+    for (int a = 0; a < 3; a++) {
+        const float pos = __fadd_rn(xyz[(size_t)i * 3 + a], shift);
+        const long long c = (long long)__fdiv_rn(__fsub_rn(pos, bbox6[a]), size);
+        bad |= c < 0 || c >= 1024;
+        key |= (unsigned long long)(c & 1023) << (10 * a);
+    }
+    if (bad) *overflow = 1;
+    keys[t] = key;
+    vals[t] = i;
+}
+
+__global__ void partition_finish4_kernel(int N, const int *__restrict__ order, const int *__restrict__ flags, const int *__restrict__ rank_incl,
+                                         int *__restrict__ cluster, int *__restrict__ starts, int *__restrict__ n_windows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4 * N) return;
+    const int v = t / N, local = t - v * N;
+    const int r = rank_incl[t] - rank_incl[v * N];  // (the variant's first element carries a flag: its inclusive rank is the base + 1)
+    cluster[(size_t)v * N + order[t]] = r;
+    int *st = starts + (size_t)v * (N + 2);
+    if (flags[t]) st[r] = local;
+    if (local == N - 1) {
+        st[r + 1] = N;
+        n_windows[v] = r + 1;
+    }
+}
+
 __global__ void boundary_flag_kernel(int N, const unsigned long long *__restrict__ skeys, int *__restrict__ flags) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N) return;
@@ -395,6 +438,44 @@ void pointops2_window_partition_launcher(int N, int b, const float *xyz, const i
     e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, N, st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
     hipLaunchKernelGGL(partition_finish_kernel, dim3(g), dim3(256), 0, st, N, order, flags, rank, cluster, starts, n_windows);
+    check_launch();
+}
+
+size_t pointops2_partitions4_workspace_bytes(int N) {
+    if (N <= 0) return 0;
+    const size_t n4 = 4 * (size_t)N;
+    return 2 * al(n4 * 8) + 3 * al((n4 + 1) * 4) + al(sort64_bytes((int)n4)) + al(scan_bytes((int)n4 + 1));
+}
+
+// cluster / order [4][N], starts [4][N+2], n_windows [4]: variant 0 small, 1 small shifted (window/2), 2 large (2 window), 3 large shifted
+// (window); *overflow = 1 when a voxel coordinate does not fit the fixed key (the outputs are then in range but meaningless)
+void pointops2_window_partitions4_launcher(int N, int b, const float *xyz, const int *offset, const float *bbox6, float window, int *cluster,
+                                           int *order, int *starts, int *n_windows, int *overflow, void *ws, size_t ws_bytes) {
+    if (N <= 0) return;
+    if ((size_t)N * 4 >= (size_t)1 << 30) { set_error("pointops2_window_partitions4: too many points"); return; }
+    if (ws_bytes < pointops2_partitions4_workspace_bytes(N)) { set_error("pointops2_window_partitions4: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    const int n4 = 4 * N;
+    char *p = reinterpret_cast<char *>(ws);
+    unsigned long long *keys_in = (unsigned long long *)p; p += al((size_t)n4 * 8);
+    unsigned long long *keys_out = (unsigned long long *)p; p += al((size_t)n4 * 8);
+    int *vals_in = (int *)p; p += al(((size_t)n4 + 1) * 4);
+    int *flags = (int *)p; p += al(((size_t)n4 + 1) * 4);
+    int *rank = (int *)p; p += al(((size_t)n4 + 1) * 4);
+    void *tmp = p;
+    size_t tmp_bytes = ws_bytes - (size_t)(p - reinterpret_cast<char *>(ws));
+    int batch_bits = 0;
+    while ((1 << batch_bits) < b) batch_bits++;
+    const int g = div_up(n4, 256);
+    (void)hipMemsetAsync(overflow, 0, sizeof(int), st);
+    hipLaunchKernelGGL(voxel_key4_kernel, dim3(g), dim3(256), 0, st, N, b, xyz, offset, bbox6, window, batch_bits, keys_in, vals_in, overflow);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const unsigned long long *)keys_in, keys_out, (const int *)vals_in, order, n4,
+                                                      0, 32 + batch_bits, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(boundary_flag_kernel, dim3(g), dim3(256), 0, st, n4, keys_out, flags);
+    e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, n4, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
+    hipLaunchKernelGGL(partition_finish4_kernel, dim3(g), dim3(256), 0, st, N, order, flags, rank, cluster, starts, n_windows);
     check_launch();
 }
 

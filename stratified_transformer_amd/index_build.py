@@ -272,10 +272,22 @@ def cell_query_cap(n_points, heads):
     return big if n_points * heads >= 96000 else small
 
 
-def stage_partitions_hip(xyz, offset, window_size):
+class _KeyOverflow(Exception):
+    """a voxel coordinate did not fit the fixed-width key of the one-sort partitions"""
+
+
+FUSED_PARTITIONS = os.environ.get("P2_PARTITIONS4", "1") != "0"
+
+
+def stage_partitions_hip(xyz, offset, window_size, one_sort=None):
     """The part of a stage's index build that needs the coordinates only: bounding box and the four window partitions
-    (grid_sample x 4, stratified_transformer.py:277,280,297,300).  One host sync (the box sizes the sort keys).  Returns the
-    context stage_index_hip continues from - a caller can run this beside the stage's FPS instead of behind it."""
+    (grid_sample x 4, stratified_transformer.py:277,280,297,300).  Returns the context stage_index_hip continues from - a caller
+    can run this beside the stage's FPS instead of behind it.
+
+    one_sort (default): all four partitions by ONE radix sort on a key of fixed width (csrc/index.hip, voxel_key4_kernel) and no
+    host sync; `overflow` (a device flag the next read-back of stage_index_hip looks at) says that a voxel coordinate needed more
+    than ten bits - stage_index_hip then comes back here with one_sort=False: one sort per partition, the key sized from the
+    bounding box on the host (one sync), any extent."""
     import numpy as np
     from . import _lib
     from ._lib import ptr
@@ -284,24 +296,37 @@ def stage_partitions_hip(xyz, offset, window_size):
     l = _lib.lib()
     w32 = np.float32(window_size)
     i32 = dict(dtype=torch.int32, device=dev)
+    if one_sort is None:
+        one_sort = FUSED_PARTITIONS
+    names = ("small", "small_shift", "large", "large_shift")
     with torch.cuda.device(dev):
         ws_bytes = int(l.pointops2_index_workspace_bytes(N))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         bbox = torch.empty(6, dtype=torch.float32, device=dev)
         _lib.call("pointops2_bbox_launcher", N, ptr(xyz), ptr(bbox), device=dev)
-        bb = np.asarray(bbox.tolist(), dtype=np.float32)   # host sync 1: sizes the radix-sort key
-        parts = {}
-        for name, size, shift in (("small", w32, np.float32(0)), ("small_shift", w32, np.float32(0.5) * w32),
-                                  ("large", np.float32(2) * w32, np.float32(0)), ("large_shift", np.float32(2) * w32, w32)):
-            nvox = 1
-            for a in range(3):
-                nvox *= int((np.float32(bb[3 + a] + shift) - bb[a]) / size) + 1
-            key_bits = max(int(nvox * b).bit_length() + 1, 8)
-            part = HipPartition(torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N + 2, **i32), torch.empty(1, **i32))
-            _lib.call("pointops2_window_partition_launcher", N, b, ptr(xyz), ptr(offset), ptr(bbox), float(size), float(shift), key_bits,
-                      ptr(part.cluster), ptr(part.order), ptr(part.starts), ptr(part.n_windows), ptr(ws), ws_bytes, device=dev)
-            parts[name] = part
-    return dict(parts=parts, ws=ws, ws_bytes=ws_bytes, bbox=bbox, w32=w32)
+        parts, overflow = {}, None
+        if one_sort and 0 < N < 2 ** 28:
+            ws_bytes = max(ws_bytes, int(l.pointops2_partitions4_workspace_bytes(N)))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            cluster, order, starts = torch.empty((4, N), **i32), torch.empty((4, N), **i32), torch.empty((4, N + 2), **i32)
+            n_windows, overflow = torch.empty(4, **i32), torch.empty(1, **i32)
+            _lib.call("pointops2_window_partitions4_launcher", N, b, ptr(xyz), ptr(offset), ptr(bbox), float(w32), ptr(cluster), ptr(order),
+                      ptr(starts), ptr(n_windows), ptr(overflow), ptr(ws), ws_bytes, device=dev)
+            for v, name in enumerate(names):
+                parts[name] = HipPartition(cluster[v], order[v], starts[v], n_windows[v:v + 1])
+        else:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            bb = np.asarray(bbox.tolist(), dtype=np.float32)   # host sync: sizes the radix-sort key
+            for name, size, shift in ((names[0], w32, np.float32(0)), (names[1], w32, np.float32(0.5) * w32),
+                                      (names[2], np.float32(2) * w32, np.float32(0)), (names[3], np.float32(2) * w32, w32)):
+                nvox = 1
+                for a in range(3):
+                    nvox *= int((np.float32(bb[3 + a] + shift) - bb[a]) / size) + 1
+                key_bits = max(int(nvox * b).bit_length() + 1, 8)
+                part = HipPartition(torch.empty(N, **i32), torch.empty(N, **i32), torch.empty(N + 2, **i32), torch.empty(1, **i32))
+                _lib.call("pointops2_window_partition_launcher", N, b, ptr(xyz), ptr(offset), ptr(bbox), float(size), float(shift), key_bits,
+                          ptr(part.cluster), ptr(part.order), ptr(part.starts), ptr(part.n_windows), ptr(ws), ws_bytes, device=dev)
+                parts[name] = part
+    return dict(parts=parts, ws=ws, ws_bytes=ws_bytes, bbox=bbox, w32=w32, overflow=overflow)
 
 
 def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_table_rows=None, cell_max_queries=0, partitions=None,
@@ -314,10 +339,21 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
     cuts cells into pieces of at most that many queries (cell_query_cap).  partitions: the result of stage_partitions_hip
     on the same xyz / offset / window_size, when the caller has already run it.  patterns=(0,) / (1,): only the plain / only the
     shifted pattern (the other BlockIndex is None) - what ONE block of the unmodified model needs (:302-317 rebuilds per block)."""
+    assert xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous()
+    ctx = partitions if partitions is not None else stage_partitions_hip(xyz, offset, window_size)
+    try:
+        return _stage_index_hip(ctx, xyz, offset, quant_size, downsample_idx, cell_table_rows, cell_max_queries, on_even, patterns)
+    except _KeyOverflow:
+        # the scene spans more than 1024 windows along an axis: partitions with host-sized keys, and the build again (the caller's
+        # context is corrected in place - pipeline.scene_pass keeps it for the per-block rebuilds of the model-order leg)
+        ctx.update(stage_partitions_hip(xyz, offset, window_size, one_sort=False))
+        return _stage_index_hip(ctx, xyz, offset, quant_size, downsample_idx, cell_table_rows, cell_max_queries, on_even, patterns)
+
+
+def _stage_index_hip(ctx, xyz, offset, quant_size, downsample_idx, cell_table_rows, cell_max_queries, on_even, patterns):
     import numpy as np
     from . import _lib
     from ._lib import ptr
-    assert xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous()
     N, b, dev = xyz.shape[0], offset.shape[0], xyz.device
     m = int(downsample_idx.shape[0])
     l = _lib.lib()
@@ -326,8 +362,8 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
     def call(name, *args):
         _lib.call(name, *args, device=dev)
 
-    ctx = partitions if partitions is not None else stage_partitions_hip(xyz, offset, window_size)
     parts, ws, ws_bytes, bbox, w32 = ctx["parts"], ctx["ws"], ctx["ws_bytes"], ctx["bbox"], ctx["w32"]
+    overflow = ctx.get("overflow")
     with torch.cuda.device(dev):
         sampled = torch.zeros(N, **i32)
         out = [None, None]   # [plain, shifted]
@@ -335,11 +371,17 @@ def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_t
 
         def finish(pend):
             """host sync: M of the patterns in `pend` (and their cell plans' totals), then the fills"""
+            flag = [] if overflow is None or ctx.get("overflow_checked") else [overflow]
             if cell_table_rows is None:
-                totals = [(m_, None) for m_ in torch.stack([p[5][N] for p in pend]).tolist()]
+                flat = torch.cat([p[5][N:N + 1] for p in pend] + flag).tolist()
+                totals = [(flat[i], None) for i in range(len(pend))]
             else:
-                flat = torch.cat([torch.cat([p[5][N:N + 1], p[6]["counts"]]) for p in pend]).tolist()
+                flat = torch.cat([torch.cat([p[5][N:N + 1], p[6]["counts"]]) for p in pend] + flag).tolist()
                 totals = [(flat[9 * i], flat[9 * i + 1:9 * i + 6]) for i in range(len(pend))]
+            if flag:
+                if flat[-1]:
+                    raise _KeyOverflow()
+                ctx["overflow_checked"] = True
             # The cell plans first: the window-centric kernels need nothing else of a pattern, so a caller that waits for `cells_ready`
             # (pipeline.scene_pass) starts its attention blocks while the pair lists - 100 us per pattern at stage 0 - are still being written.
             fills = []

@@ -278,6 +278,8 @@ def geometry_stream(device, which=0):
 
 
 EVEN_FIRST = os.environ.get("P2_EVEN_FIRST", "1") != "0"  # the first stage's first block is enqueued from inside its index build
+SPECULATION = {"passes": 0, "reruns": 0}  # speculated passes / how many of them had to be run again (an exact tie among later-stage samples)
+SPECULATE = os.environ.get("P2_SPECULATE", "1") != "0"  # later stages' samples are taken as the identity prefix while the sampler verifies them
 INDEX_THREAD = os.environ.get("P2_INDEX_THREAD", "0") == "1"  # measured: 16.2 ms against 15.5 ms per pass (the two host threads contend), so opt-in
 
 
@@ -343,9 +345,10 @@ def _block_tensors(blk):
     return t + (tuple(blk.cells.tensors()) if getattr(blk, "cells", None) is not None else ())
 
 
-def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0, cells=False, shard=None):
+def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0, cells=False, shard=None,
+               speculate=None):
     """Runs the whole unit once (both phases of scene_pass_phases back to back).  Returns (states, results)."""
-    gen = scene_pass_phases(xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane, cells=cells, shard=shard)
+    gen = scene_pass_phases(xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane, cells=cells, shard=shard, speculate=speculate)
     next(gen)
     try:
         next(gen)
@@ -355,7 +358,7 @@ def scene_pass(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, 
 
 
 def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap=True, use_hip_index=True, fused=False, lane=0,
-                      inputs_resident=False, offset_host=None, cells=False, shard=None):
+                      inputs_resident=False, offset_host=None, cells=False, shard=None, speculate=None):
     """Generator form of scene_pass: the first next() enqueues the geometry chain of ALL stages (no host sync in
     it) and yields; the second runs the index builds (which stop the host: key width, pair count) and the attention
     blocks, and returns (states, results) through StopIteration.  passes_in_flight puts the first phase of the next
@@ -372,8 +375,19 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     lane: which set of side streams the pass uses.  Two passes over different batches that are enqueued under
     different current streams, with different lanes and different `states`, share no stream and no tensor they
     write, so the device may run them side by side (passes_in_flight): the sampling chain of the next batch - one
-    CU wide, and a function of the coordinates alone - then runs beside the attention blocks of this one."""
+    CU wide, and a function of the coordinates alone - then runs beside the attention blocks of this one.
+
+    speculate (default: on for a pass on its own with overlap, P2_SPECULATE=0 turns it off): every cloud after the first is the output
+    of an FPS kept in selection order (TransitionDown, :103-104), and FPS of such a cloud returns 0, 1, 2, ... unless two candidates
+    tie exactly (csrc/fps_bucket.hip, identity-prefix verification).  The index builds, the next clouds and the kNN queries of those
+    stages therefore take the identity prefix AT ONCE, the sampler - which verifies exactly that prefix and samples on where it
+    fails - runs beside them on the geometry stream, and the pass compares the two at its end: equal (always, ties aside) means
+    every tensor of the pass is what the unspeculated pass computes; unequal, the pass is run again without speculation.  Nothing
+    is skipped - the samplers run in full - they just no longer stand between one stage's blocks and the next's."""
     timer = timer or Timer(False)
+    if speculate is None:
+        speculate = SPECULATE and overlap and not inputs_resident and use_hip_index
+    call_args = (xyz, offset, cfg, states, timer, seed, overlap, use_hip_index, fused, lane, inputs_resident, offset_host, cells, shard)
     # Tensors that are allocated under one stream and read by kernels of another (index tensors and cell plans: index stream ->
     # main; samples, clouds, offsets: geometry / upload streams -> the others) are kept alive in `keep` until an event recorded
     # at the END of the pass on the main stream has completed (_retire), instead of Tensor.record_stream(): that makes the
@@ -445,18 +459,49 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
             keep.extend(plan_dev[1:] + strat_dev)
     level = [0]
 
+    checks = []      # 0-d bool tensors (geometry stream): a sampler's output differs from the identity prefix that was used in its place
+    ordered = set()  # ids of clouds that are an FPS output in selection order
+    guesses = {}     # id of such a cloud -> the identity prefix its stratified sampling is expected to return (exists with the cloud)
+
+    def prefix(off_host, new_off_host):
+        """the identity prefix of every batch element: rows start_b ... start_b + count_b - 1"""
+        if len(off_host) == 1:
+            return torch.arange(new_off_host[0], dtype=torch.int32, device=dev)
+        starts = [0] + list(off_host[:-1])
+        counts = [new_off_host[0]] + [new_off_host[i] - new_off_host[i - 1] for i in range(1, len(new_off_host))]
+        return torch.cat([torch.arange(s_, s_ + c_, dtype=torch.int32, device=dev) for s_, c_ in zip(starts, counts)])
+
     def transition(x, off, off_host):
         """TransitionDown's sampling + grouping indices (:98-106), on the geometry stream"""
         level[0] += 1
         n_off_host, n_offset = plan_host[level[0]], plan_dev[level[0]]
+        if speculate and id(x) in ordered:
+            # the next cloud is the identity prefix of this one: it exists NOW (kNN stream), the sampler verifies it beside
+            with torch.cuda.stream(knn_s):
+                pred = prefix(off_host, n_off_host)
+                n_xyz = x[:n_off_host[0]] if len(off_host) == 1 else x[pred.long(), :].contiguous()
+                guesses[id(n_xyz)] = prefix(n_off_host, strat_host[level[0]])
+                ready = torch.cuda.Event()
+                ready.record(knn_s)
+                cloud_ready[level[0]] = ready
+                knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, x, n_xyz, off, n_offset)
+            geo.wait_event(ready)  # (pred)
+            idx = timer.run("fps/transition", P.furthestsampling, x, off, n_offset)
+            checks.append((idx != pred).any())
+            ordered.add(id(n_xyz))
+            keep.extend((x, n_xyz, off, n_offset, pred, idx))
+            return n_xyz, n_offset, n_off_host, knn_idx
         idx = timer.run("fps/transition", P.furthestsampling, x, off, n_offset)
         n_xyz = x[idx.long(), :].contiguous()
+        if speculate:
+            guesses[id(n_xyz)] = prefix(n_off_host, strat_host[level[0]])
         ready = torch.cuda.Event()
         ready.record(geo)
         cloud_ready[level[0]] = ready
         if overlap:  # the grouping query leaves the sampling chain here
             knn_s.wait_stream(geo)
             keep.extend((x, n_xyz, off, n_offset))
+        ordered.add(id(n_xyz))
         with torch.cuda.stream(knn_s):
             knn_idx, _ = timer.run("knn/k16", P.knnquery, cfg.k, x, n_xyz, off, n_offset)
         return n_xyz, n_offset, n_off_host, knn_idx
@@ -480,21 +525,28 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         """geometry stream: samples for this stage's stratified keys, then on to the next stage's points"""
         x, off, off_host = clouds[si]
         with on_geo():
+            guess = guesses.get(id(x)) if (speculate and id(x) in ordered) else None
+            if guess is not None and level[0] in cloud_ready:
+                geo.wait_event(cloud_ready[level[0]])
             ds = timer.run("fps/stratified", P.furthestsampling, x, off, strat_dev[level[0]])
-            ev_ds = torch.cuda.Event()
-            ev_ds.record(geo)
+            if guess is not None:
+                checks.append((ds != guess).any())
+                ev_ds = None  # the index build takes `guess` and waits for the cloud alone
+            else:
+                ev_ds = torch.cuda.Event()
+                ev_ds.record(geo)
             knn_idx = None
             if si < len(cfg.stages) - 1:
                 n_xyz, n_off, n_off_host, knn_idx = transition(x, off, off_host)
                 clouds[si + 1] = (n_xyz, n_off, n_off_host)
-        geo_out[si] = (ds, ev_ds, knn_idx)
+        geo_out[si] = (ds if guess is None else guess, ev_ds, knn_idx, ds)
 
     def index(si, on_even=None):
         x, off, _ = clouds[si]
-        ds, ev_ds, _ = geo_out[si]
+        ds, ev_ds, _, ds_sampled = geo_out[si]
         st = cfg.stages[si]
         if overlap:
-            keep.extend((ds, x, off))
+            keep.extend((ds, ds_sampled, x, off))
         with torch.cuda.stream(idx_s):
             parts_ctx = None
             if use_hip_index:
@@ -504,7 +556,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
                 if overlap and lvl in cloud_ready:
                     idx_s.wait_event(cloud_ready[lvl])
                 parts_ctx = timer.run("index/partitions", index_build.stage_partitions_hip, x, off, st.window_size)
-            if overlap:
+            if overlap and ev_ds is not None:
                 idx_s.wait_event(ev_ds)
             if use_hip_index:
                 even, odd, _ = timer.run("index/build", index_build.stage_index_hip, x, off, st.window_size, st.quant_size, ds,
@@ -575,7 +627,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
             if even.owner is None:
                 even.owner = _sh.window_owners(even.parts["large"], [even.offsets, odd.offsets], shard[1])
             odd.owner = even.owner   # one ownership per stage: the rows do not move between the blocks
-        ds, _, knn_idx = geo_out[si]
+        _, _, knn_idx, ds = geo_out[si]
         if overlap:
             cells_only = str(fused).startswith("cell") and shard is None and odd is not None and odd.cells_ready is not None
             main.wait_event(odd.cells_ready if cells_only else ev_idx)  # (same stream: the shifted pattern's plan is the later one)
@@ -632,7 +684,23 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
         main.wait_stream(knn_s)
         main.wait_stream(idx_s)
     timer.run("mark/streams_joined", lambda: None)
+    if checks:
+        with on_geo():
+            wrong = torch.stack(checks).any().to("cpu", non_blocking=True)  # (pinned staging by the allocator; complete at the event)
+            seen = torch.cuda.Event()
+            seen.record(geo)
+        keep.extend(checks)
     _retire(dev, lane, main, keep)
+    if checks:
+        SPECULATION["passes"] += 1
+        seen.synchronize()  # the geometry stream has long finished: the blocks of the last stages are what the device still holds
+        if bool(wrong):
+            # an exact tie among the samples of a later stage: the identity prefix was not what the sampler returns - once more, waiting
+            # for every sampler as the reference does (same states: the synthetic tensors are inputs, the gradients are reset per block)
+            SPECULATION["reruns"] += 1
+            torch.cuda.synchronize(dev)
+            a = call_args
+            return scene_pass(a[0], a[1], a[2], states, a[4], a[5], a[6], a[7], a[8], a[9], cells=a[12], shard=a[13], speculate=False)
     return states, results
 
 

@@ -600,6 +600,44 @@ def test_index_build_hip_matches_oracle_and_torch_path(n, nbatch, w, quant):
         assert torch.equal(tb.index_1, blk.index_1) and torch.equal(tb.rel_idx, blk.rel_idx) and torch.equal(tb.offsets, blk.offsets)
 
 
+@pytest.mark.parametrize("sizes,w", [([6000], 0.16), ([2500, 1500, 3000], 0.32), ([70, 3, 900], 0.64)])
+def test_partitions_by_one_sort_equal_the_four_single_sorts(sizes, w):
+    """stage_partitions_hip's default (all four grid_sample partitions by ONE radix sort on a fixed-width key, no host sync) gives the
+    arrays of the four single sorts with host-sized keys, entry for entry."""
+    from stratified_transformer_amd import index_build, scene
+    xyz_np, offset = scene.make_batch(sizes, seed=sum(sizes))
+    xyz, off = dev(xyz_np), dev(offset)
+    one = index_build.stage_partitions_hip(xyz, off, w, one_sort=True)
+    four = index_build.stage_partitions_hip(xyz, off, w, one_sort=False)
+    assert int(one["overflow"].item()) == 0 and four["overflow"] is None
+    for name in ("small", "small_shift", "large", "large_shift"):
+        a, b = one["parts"][name], four["parts"][name]
+        nw = int(b.n_windows.item())
+        assert int(a.n_windows.item()) == nw
+        assert torch.equal(a.cluster, b.cluster) and torch.equal(a.order, b.order), name
+        assert torch.equal(a.starts[: nw + 1], b.starts[: nw + 1]), name
+
+
+def test_index_build_of_a_scene_wider_than_the_fixed_key():
+    """More than 1024 windows along an axis: the one-sort partitions flag the overflow, stage_index_hip notices at its read-back and
+    builds the partitions one by one (host-sized keys) - the pair lists are the oracle's."""
+    from oracle import index_ref
+    from stratified_transformer_amd import index_build, scene
+    n, w, quant = 2400, 0.16, 0.01
+    xyz_np, offset = scene.make_batch([n], seed=77)
+    xyz_np = np.ascontiguousarray(xyz_np * np.array([250.0, 1.0, 1.0], np.float32))   # hundreds of metres long: more than 1024 windows of 0.16 m
+    ds = np.sort(np.random.default_rng(3).permutation(n)[: n // 8 + 1]).astype(np.int32)
+    xyz = dev(xyz_np)
+    ctx = index_build.stage_partitions_hip(xyz, dev(offset), w)
+    assert int(ctx["overflow"].item()) == 1
+    even, odd, _ = index_build.stage_index_hip(xyz, dev(offset), w, quant, dev(ds), partitions=ctx)
+    assert ctx["overflow"] is None  # (the context was rebuilt)
+    for par, blk in enumerate((even, odd)):
+        want = index_ref.build_stage_indices(torch.from_numpy(xyz_np), offset, w, quant, torch.from_numpy(ds), par, div_mode="cuda")
+        for field in ("index_0", "index_1", "offsets", "rel_idx"):
+            assert np.array_equal(_np(getattr(blk, field)), want[field].numpy()), (par, field)
+
+
 def test_query_shard_ops_with_more_keys_than_queries(P):
     """What a rank of a sharded scene runs: CSR rows = its own queries, k/v rows = all points.  The rows
     of the sharded results equal the unsharded ones; key-side gradients sum over shards to the full ones."""
@@ -1418,6 +1456,48 @@ def test_installed_window_attention_alone_takes_the_references_arguments(golden)
     for p, n in ((attn.relative_pos_query_table, "wa_grad_table_q"), (attn.relative_pos_key_table, "wa_grad_table_k"),
                  (attn.relative_pos_value_table, "wa_grad_table_v"), (attn.qkv.weight, "wa_grad_qkv_weight")):
         np.testing.assert_allclose(_np(p.grad), g[n], **TTOL)
+
+
+def _same_pass(res_a, res_b):
+    assert len(res_a) == len(res_b)
+    for a, b in zip(res_a, res_b):
+        assert a["n"] == b["n"] and torch.equal(a["downsample_idx"], b["downsample_idx"]), a["stage"]
+        for name in ("even", "odd"):
+            for field in ("index_1", "offsets", "rel_idx"):
+                assert torch.equal(getattr(a[name], field), getattr(b[name], field)), (a["stage"], name, field)
+            ca, cb = a[name].cells, b[name].cells  # (the plans' arrays are allocated for N entries: only their counts are compared; `out` below covers the rest)
+            assert (ca.n_cells, ca.n_pairs, ca.n_keyslots, ca.nk_max) == (cb.n_cells, cb.n_pairs, cb.n_keyslots, cb.nk_max), (a["stage"], name)
+        if "transition_knn" in a:
+            assert torch.equal(a["transition_knn"], b["transition_knn"])
+        assert torch.equal(a["out"], b["out"])
+
+
+def test_speculated_identity_prefix_pass_equals_the_waiting_pass(P):
+    """pipeline.scene_pass takes the later stages' samples as the identity prefix while the sampler verifies them (speculate):
+    every tensor of the pass must be what the pass that waits for each sampler computes - on a room (no ties: no rerun), on a
+    batch of three rooms under the ScanNet config (a TransitionDown first: every attention stage is speculated), and on a LATTICE,
+    where exact ties break the identity prefix, the check at the end of the pass notices and the pass is run again."""
+    from stratified_transformer_amd import pipeline, scene
+    lattice = np.stack(np.meshgrid(*[np.arange(21, dtype=np.float32) * np.float32(0.04)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    lattice = np.ascontiguousarray(lattice[np.random.default_rng(4).permutation(len(lattice))])
+    cases = [("room", pipeline.s3dis_config(), scene.make_room(20000, seed=12), np.array([20000], np.int32), False),
+             ("batch", pipeline.scannet_config(), *scene.make_batch([9000, 6000, 8000], seed=41, voxel=0.02), False),
+             ("lattice", pipeline.s3dis_config(), lattice, np.array([len(lattice)], np.int32), True)]
+    for name, cfg, xyz, offset, expect_rerun in cases:
+        x_d, o_d = dev(xyz), dev(offset)
+        states, waited = pipeline.scene_pass(x_d, o_d, cfg, seed=5, fused="cell", speculate=False)
+        torch.cuda.synchronize()
+        grads = [[t.grad.clone() for t in (s.q, s.k, s.v) + tuple(s.tables)] for s in states]
+        before = dict(pipeline.SPECULATION)
+        _, guessed = pipeline.scene_pass(x_d, o_d, cfg, states, fused="cell", speculate=True)
+        torch.cuda.synchronize()
+        assert pipeline.SPECULATION["passes"] == before["passes"] + 1, name
+        if expect_rerun:
+            assert pipeline.SPECULATION["reruns"] == before["reruns"] + 1, (name, pipeline.SPECULATION, before)
+        _same_pass(waited, guessed)
+        for s, want in zip(states, grads):
+            for t, w in zip((s.q, s.k, s.v) + tuple(s.tables), want):
+                torch.testing.assert_close(t.grad, w, rtol=1e-4, atol=1e-4)
 
 
 def test_model_call_order_pass_equals_the_operator_pass(P):

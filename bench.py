@@ -143,7 +143,7 @@ def run_gpu(args, rank, world):
         """what the report needs of a pass's results (sizes only)"""
         return [dict(stage=r["stage"], n=r["n"], M_even=r["M_even"], M_odd=r["M_odd"]) for r in res]
 
-    def single_pass_leg(fused):
+    def single_pass_leg(fused, overlap=True):
         # A leg keeps NOTHING of its passes but sizes and event timers: with the tensors of an earlier leg's last pass still alive
         # (pair lists, outputs) the next leg's backward kernels ran 45 % slower for the whole leg - 16.6 instead of 14.2 ms per
         # pass at --steps 20 (tools/leg_trace2.py; no device allocations involved: the same kernels on memory the allocator
@@ -151,7 +151,7 @@ def run_gpu(args, rank, world):
         nonlocal states
         st, res = states, None
         for _ in range(max(args.warmup, 1)):
-            st, res = pipeline.scene_pass(xyz, offset, cfg, st, fused=fused, shard=shard)
+            st, res = pipeline.scene_pass(xyz, offset, cfg, st, fused=fused, shard=shard, overlap=overlap)
         live = pipeline.Timer(True, only=("attn", "fps/", "comm/") + (("index/",) if shard else ()))
         if shard:
             from stratified_transformer_amd import sharding
@@ -160,7 +160,7 @@ def run_gpu(args, rank, world):
         with no_gc():
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                st, res = pipeline.scene_pass(xyz, offset, cfg, st, live, fused=fused, shard=shard)
+                st, res = pipeline.scene_pass(xyz, offset, cfg, st, live, fused=fused, shard=shard, overlap=overlap)
             barrier()
             elapsed = max_over_ranks(time.perf_counter() - t0)
         states = st
@@ -175,7 +175,9 @@ def run_gpu(args, rank, world):
     # (sharded scene: operator_api = queries cut by range, all-gather k / v; cell = every world-th cell of the size-sorted list per
     #  rank, all-gather q / k / v, reduce-scatter of the output - sharding.py)
     out["single_cell"] = single_pass_leg("cell")
+    out["speculation"] = dict(pipeline.SPECULATION)
     if not shard:
+        out["single_cell_one_stream"] = single_pass_leg("cell", overlap=False)
         out["single_model"] = single_pass_leg("model")
     if not shard:  # BASELINE configs 2 ("fwd only") and 3 ("fp32 vs bf16") on the same scene
         out["single_fwd"] = single_pass_leg("cell_fwd")
@@ -506,8 +508,11 @@ def main():
             return dict(ms_per_step=round(ms, 3), value=round(N_POINTS * scenes / (ms / 1e3), 1))
 
         cell, ops = leg(run["single_cell"]["elapsed"]), leg(run["single_ops"]["elapsed"])
-        cell["reached_by"] = ("stratified_transformer_amd.install(fast_layers=True): BasicLayer.forward / WindowAttention.forward of the unmodified model file "
-                              "rebound to stratified_transformer_amd.layers (index built once per stage, fused.cell_attention per block)")
+        cell["reached_by"] = ("pipeline.scene_pass: the index build and kernels of stratified_transformer_amd.install(fast_layers=True) (index built once per stage, "
+                              "fused.cell_attention per block) under the package's own schedule - sampling chain on a side stream beside the blocks, later stages' "
+                              "samples taken as the identity prefix while the sampler verifies them; a training loop that calls the package's pass, not the "
+                              "unmodified model file (that one: cell_model_order)")
+        cell["speculation"] = run.get("speculation")
         ops["reached_by"] = ("the five operators of the drop-in pointops API on a pair list built once per stage (index_build.stage_index_hip): a caller that "
                              "owns its BasicLayer but keeps the reference's operators")
         extra_legs = {}
@@ -519,6 +524,13 @@ def main():
                      "operator, rel-pos index by torch ops + two range asserts (host syncs), attn + bias, scatter_softmax shim; the block's pattern is rebuilt "
                      "for every block beyond the first two (:302-317) with the package's device index build - the model's own torch index build "
                      "(grid_sample / get_indice_pairs / sort) is NOT in this number (it lives in the model file and cannot run on the GPU box): a lower bound")
+        if "single_cell_one_stream" in run:
+            extra_legs["cell_model_order"] = dict(
+                leg(run["single_cell_one_stream"]["elapsed"]),
+                reached_by="stratified_transformer_amd.install(fast_layers=True): BasicLayer.forward / WindowAttention.forward of the unmodified model file rebound "
+                           "to stratified_transformer_amd.layers",
+                note="the same pass with every call on ONE stream in the model's order (sampler -> index build -> blocks -> TransitionDown's sampler -> kNN -> "
+                     "next stage), which is what the rebound methods of the unmodified model issue: no side stream, nothing speculated")
         if "single_fwd" in run:
             extra_legs["cell_forward_only"] = dict(leg(run["single_fwd"]["elapsed"]), note="BASELINE config 2: the same pass without the blocks' backward")
             extra_legs["cell_bf16_storage"] = dict(leg(run["single_bf16"]["elapsed"]), note="BASELINE config 3, second leg: q / k / v / tables stored as bf16, "

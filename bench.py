@@ -183,6 +183,9 @@ def run_gpu(args, rank, world):
         out["single_fwd"] = single_pass_leg("cell_fwd")
         out["single_bf16"] = single_pass_leg("cell_bf16")
 
+    if not shard:
+        out["installed_layers"] = installed_layers_leg(args, cfg, xyz, offset, barrier, max_over_ranks)
+
     # every component, from passes run again with events around every op (not the timed region)
     timer = pipeline.Timer(True)
     for _ in range(args.steps):
@@ -243,6 +246,62 @@ def run_gpu(args, rank, world):
         del res_cell
     out["states"] = states
     return out
+
+
+def installed_layers_leg(args, cfg, xyz, offset, barrier, max_over_ranks):
+    """The installed layer forwards under the model's own call order: four stand-in BasicLayers (stratified_transformer_amd.standin:
+    the reference's attribute names, call structure and parameter shapes; the reference itself cannot travel to the GPU box) strung
+    as Stratified.forward strings them (:470-477), forward + backward on the bench scene.  NOT the metric's unit: a layer also runs
+    its qkv / proj / MLP Linear layers, LayerNorms and TransitionDown's grouping + Linear + max-pool, which the unit leaves out."""
+    import torch
+    from stratified_transformer_amd import layers, standin
+    from stratified_transformer_amd import pointops as P
+    torch.manual_seed(0)
+    dev = xyz.device
+    st = cfg.stages
+    net = torch.nn.ModuleList([standin.BasicLayer(cfg.downsample_scale, s.depth, s.channels, s.num_heads, s.window_size, s.quant_size, ratio=cfg.ratio, k=cfg.k,
+                                                  out_channels=st[i + 1].channels if i + 1 < len(st) else None) for i, s in enumerate(st)]).to(dev)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if "relative_pos" in name:
+                p.normal_(0.0, 0.02)
+    feats0 = torch.randn(xyz.shape[0], st[0].channels, device=dev)
+
+    def step():
+        # nothing is carried over from the step before (the same tensor object is fed again): sampler states and what the layers
+        # remember about the clouds are dropped, as pipeline.scene_pass does at the start of every pass
+        P.clear_caches()
+        layers.forget_clouds()
+        net.zero_grad(set_to_none=True)
+        f, x, o = feats0.clone().requires_grad_(True), xyz, offset
+        loss = None
+        for layer in net:
+            f_out, _, _, f, x, o = layer(f, x, o)
+            term = f_out.square().mean()
+            loss = term if loss is None else loss + term
+        loss.backward()
+
+    res = {}
+    chain_was = layers.CHAIN
+    try:
+        layers.patch_classes(standin.BasicLayer, standin.WindowAttention, standin.TransitionDown)
+        for name, chain in (("one_stream", False), ("chained", True)):
+            layers.CHAIN = chain
+            before = dict(layers.STATS)
+            for _ in range(max(args.warmup, 1)):
+                step()
+            barrier()
+            with no_gc():
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                barrier()
+                res[name] = max_over_ranks(time.perf_counter() - t0)
+            res[name + "_stats"] = {k: layers.STATS[k] - before[k] for k in before}
+    finally:
+        layers.CHAIN = chain_was
+        layers.uninstall_fast_layers()
+    return res
 
 
 def component_table(timer, steps):
@@ -531,6 +590,17 @@ def main():
                            "to stratified_transformer_amd.layers",
                 note="the same pass with every call on ONE stream in the model's order (sampler -> index build -> blocks -> TransitionDown's sampler -> kNN -> "
                      "next stage), which is what the rebound methods of the unmodified model issue: no side stream, nothing speculated")
+        if "installed_layers" in run:
+            il = run["installed_layers"]
+            extra_legs["installed_layers_model"] = dict(
+                one_stream_ms=round(il["one_stream"] / K * 1e3, 3), chained_ms=round(il["chained"] / K * 1e3, 3), chained_stats=il["chained_stats"],
+                reached_by="stratified_transformer_amd.install(fast_layers=True) on the unmodified model file",
+                note="NOT the metric's unit: forward + backward of four whole BasicLayers (stand-in containers with the reference's attribute names, "
+                     "call structure and parameter shapes, S3DIS config) strung as Stratified.forward strings them on the same scene - attention "
+                     "blocks INCLUDING their qkv / proj / MLP Linear layers and LayerNorms, TransitionDown's grouping + Linear + max-pool.  one_stream: "
+                     "every call on the caller's stream in the model's order; chained: the installed forwards put the samplers and the "
+                     "TransitionDown geometry on side streams and take later stages' samples as the identity prefix while the sampler verifies them "
+                     "(layers.py) - the schedule of single_pass.cell under the unmodified model's call order")
         if "single_fwd" in run:
             extra_legs["cell_forward_only"] = dict(leg(run["single_fwd"]["elapsed"]), note="BASELINE config 2: the same pass without the blocks' backward")
             extra_legs["cell_bf16_storage"] = dict(leg(run["single_bf16"]["elapsed"]), note="BASELINE config 3, second leg: q / k / v / tables stored as bf16, "

@@ -230,6 +230,9 @@ class FurthestSampling(Function):
         if ent is not None:
             _FPS_CACHE.move_to_end(key)
             have = ent["counts"]
+            # the kept state may have been produced under another stream (a sampler prefetched beside the blocks): order behind it
+            if ent.get("event") is not None and ent.get("stream") != torch.cuda.current_stream(xyz.device):
+                torch.cuda.current_stream(xyz.device).wait_event(ent["event"])
             if all(w <= h for w, h in zip(want, have)):
                 starts = [0] + ent["new_offs"][:-1]
                 if b == 1:
@@ -256,8 +259,10 @@ class FurthestSampling(Function):
             l.pointops2_set_fps_resume(None, None)
         del tmp
         if n_max >= 2048:  # the bucketed kernel ran: its state can serve / resume later requests
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(xyz.device))
             _FPS_CACHE[key] = dict(xyz=xyz, ws=ws, idx=idx, new_offset=new_offset, new_offs=list(new_offs),
-                                   counts=want)
+                                   counts=want, event=done, stream=torch.cuda.current_stream(xyz.device))
             while len(_FPS_CACHE) > _FPS_CACHE_SIZE:
                 _FPS_CACHE.popitem(last=False)
             return idx.clone()

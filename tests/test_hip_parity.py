@@ -1381,13 +1381,17 @@ def test_data_prepare_on_device_against_the_reference_golden(tmp_path):
         dataprep.load_scannet_pth(bad)
 
 
-def test_installed_fast_layers_against_the_reference_layer():
+@pytest.mark.parametrize("mode", ["two_classes", "with_transition", "one_stream"])
+def test_installed_fast_layers_against_the_reference_layer(mode):
     """the fast path reachable from the model's own call sites.  tests/golden/basic_layer_1400.npz holds what the
     REFERENCE's BasicLayer (depth 2: a plain and a shifted block, TransitionDown, two batch elements) computes on CPU - output,
     down-sampled output / coordinates / offsets, and the gradient of the input and of every parameter (make_golden_layer.py).
     Here the installable forwards (layers.basic_layer_forward / window_attention_forward: FPS, stage_index_hip once per stage,
     fused.cell_attention per block, the modules' own parameters) run under stand-in containers with the reference's attribute
-    names and state-dict keys.  Integers bit-exact; floats within 1e-3 of the tensor's scale (measured ~1e-5)."""
+    names and state-dict keys.  Integers bit-exact; floats within 1e-3 of the tensor's scale (measured ~1e-5).
+    Modes: BasicLayer + WindowAttention rebound (the stage's samplers run on a side stream, the container's own TransitionDown picks
+    the samples up from the sampler's kept state); TransitionDown rebound too (its geometry prefetched beside the blocks); everything on
+    the caller's stream (layers.CHAIN off)."""
     import os
     import model_standin as ms
     from stratified_transformer_amd import fused, layers
@@ -1402,14 +1406,21 @@ def test_installed_fast_layers_against_the_reference_layer():
         calls["cell"] += 1
         return real(*a, **kw)
     fused.cell_attention = counting
+    chain_was, before = layers.CHAIN, dict(layers.STATS)
     try:
-        assert layers.patch_classes(ms.BasicLayer, ms.WindowAttention) == [ms.BasicLayer, ms.WindowAttention]
+        layers.CHAIN = mode != "one_stream"
+        classes = [ms.BasicLayer, ms.WindowAttention] + ([ms.TransitionDown] if mode == "with_transition" else [])
+        assert layers.patch_classes(*classes) == classes
         feats = _leaf(g["feats"])
         f, x, o, f_down, x_down, o_down = layer(feats, dev(g["xyz"]), dev(g["offset"]))
         ((f * dev(g["grad_out"])).sum() + (f_down * dev(g["grad_out_down"])).sum()).backward()
+        torch.cuda.synchronize()
     finally:
         fused.cell_attention = real
+        layers.CHAIN = chain_was
         layers.uninstall_fast_layers()
+    assert layers.STATS["transitions_prefetched"] - before["transitions_prefetched"] == (0 if mode == "one_stream" else 1)
+    assert ms.TransitionDown.forward is not layers.transition_down_forward
     assert calls["cell"] == depth                                      # every block ran as ONE fused function on its cell plan
     assert ms.BasicLayer.forward is not layers.basic_layer_forward      # uninstall restores the classes
     assert np.array_equal(_np(o_down), g["offset_down"]) and np.array_equal(_np(x_down), g["xyz_down"])   # FPS: the reference's samples
@@ -1422,6 +1433,77 @@ def test_installed_fast_layers_against_the_reference_layer():
     close(_np(feats.grad), g["grad_feats"], "grad_feats")
     for name, p in layer.named_parameters():
         close(_np(p.grad), g["grad." + name], "grad." + name)
+
+
+def _stack_of_layers(ms, seed):
+    torch.manual_seed(seed)
+    spec = [(48, 3, 0.16, 0.01, 96), (96, 6, 0.32, 0.02, 192), (192, 12, 0.64, 0.04, None)]
+    net = torch.nn.ModuleList([ms.BasicLayer(8, 2, c, h, w, q, ratio=0.25, k=16, out_channels=c_out) for c, h, w, q, c_out in spec]).cuda()
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if "relative_pos" in name:
+                p.copy_(torch.randn_like(p) * 0.3)
+    return net
+
+
+def _run_stack(net, feats, xyz, offset):
+    outs = []
+    for layer in net:
+        f, xyz_same, off_same, f_down, xyz_down, off_down = layer(feats, xyz, offset)
+        outs.append((f, xyz_down, off_down))
+        feats, xyz, offset = f_down, xyz_down, off_down
+    sum(o[0].square().sum() for o in outs).backward()
+    torch.cuda.synchronize()
+    return outs
+
+
+@pytest.mark.parametrize("cloud", ["rooms", "lattice"])
+def test_installed_layers_chain_equals_the_one_stream_order(cloud):
+    """Three stages the way Stratified.forward strings them (:470-477: every stage's down-sampled cloud is the next stage's input)
+    with BasicLayer / WindowAttention / TransitionDown rebound: the geometry chain (samplers and TransitionDown geometry on side
+    streams, later stages' samples taken as the identity prefix while the sampler verifies them) must give what the same layers give
+    with every call on the caller's stream - coordinates, offsets bit-identical; outputs and every parameter gradient to 1e-4 of the
+    tensor's scale.  On a lattice the identity prefix fails on a tie: the stage runs again with the sampler's answer."""
+    import model_standin as ms
+    from stratified_transformer_amd import layers, scene
+    if cloud == "rooms":
+        xyz_np, offset_np = scene.make_batch([9000, 7000], seed=55)
+    else:
+        xyz_np = np.stack(np.meshgrid(*[np.arange(22, dtype=np.float32) * np.float32(0.04)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        xyz_np = np.ascontiguousarray(xyz_np[np.random.default_rng(6).permutation(len(xyz_np))])
+        offset_np = np.array([len(xyz_np)], np.int32)
+    net = _stack_of_layers(ms, 3)
+    feats0 = torch.randn(xyz_np.shape[0], 48, generator=torch.Generator().manual_seed(1)).cuda()
+    results = {}
+    chain_was = layers.CHAIN
+    try:
+        layers.patch_classes(ms.BasicLayer, ms.WindowAttention, ms.TransitionDown)
+        for chain in (False, True):
+            layers.CHAIN = chain
+            before = dict(layers.STATS)
+            net.zero_grad(set_to_none=True)
+            feats = feats0.clone().requires_grad_(True)
+            outs = _run_stack(net, feats, dev(xyz_np), dev(offset_np))
+            results[chain] = (outs, feats.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()},
+                              {k: layers.STATS[k] - before[k] for k in before})
+    finally:
+        layers.CHAIN = chain_was
+        layers.uninstall_fast_layers()
+    (o0, g0, pg0, st0), (o1, g1, pg1, st1) = results[False], results[True]
+    assert st0["speculated"] == 0 and st1["speculated"] == 2 and st1["transitions_prefetched"] == 2, (st0, st1)
+    assert (st1["reruns"] > 0) == (cloud == "lattice"), st1
+
+    def close(a, b, name):
+        a, b = a.detach(), b.detach()
+        tol = 1e-4 * max(float(b.abs().max()), 1e-6)
+        assert a.shape == b.shape and float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), tol)
+    for si, ((fa, xa, oa), (fb, xb, ob)) in enumerate(zip(o0, o1)):
+        close(fb, fa, "stage %d out" % si)
+        if xa is not None:
+            assert torch.equal(xa, xb) and torch.equal(oa, ob), si
+    close(g1, g0, "grad feats")
+    for n in pg0:
+        close(pg1[n], pg0[n], "grad " + n)
 
 
 def test_installed_window_attention_alone_takes_the_references_arguments(golden):

@@ -225,6 +225,13 @@ void pointops2_window_partition_launcher(int N, int b, const float *xyz, const i
  * window): cluster / order [4][N], starts [4][N+2], n_windows [4], same contents as four partition calls.  The key is of fixed width
  * (ten bits per voxel coordinate: no bounding-box read-back); *overflow = 1 when a coordinate does not fit - the outputs are then
  * meaningless (but in range) and the caller builds the partitions one by one. */
+/* Rows in window order: order [N] = the rows of a CSR pair list sorted by their first partner (rows of one window become neighbours).
+ * pointops2_set_row_order(order, N) makes the operators' pair walkers (A1 / A2 / A4 forward and backward, by query and by key) take
+ * their rows in that order, eight runs over the eight XCDs, whenever a launch walks exactly N rows: same results (the sums of a row
+ * do not change), the gathers of neighbouring waves hit the second-level cache.  nullptr (the default): rows by index. */
+size_t pointops2_row_order_workspace_bytes(int N);
+void pointops2_row_order_launcher(int N, int M, const int *offsets, const int *index1, int *order, void *ws, size_t ws_bytes);
+void pointops2_set_row_order(const int *order, int n_rows);
 size_t pointops2_partitions4_workspace_bytes(int N);
 void pointops2_window_partitions4_launcher(int N, int b, const float *xyz, const int *offset, const float *bbox6, float window,
                                            int *cluster, int *order, int *starts, int *n_windows, int *overflow, void *ws,

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pointops2_bbox_launcher": [I, P, P],
     "pointops2_window_partition_launcher": [I, I, P, P, P, F, F, I, P, P, P, P, P, Z],
     "pointops2_window_partitions4_launcher": [I, I, P, P, P, F, P, P, P, P, P, P, Z],
+    "pointops2_row_order_launcher": [I, I, P, P, P, P, Z],
+    "pointops2_set_row_order": [P, I],
     "pointops2_window_coord_launcher": [I, P, P, F, I, P],
     "pointops2_sampled_buckets_launcher": [I, I, P, P, P, P, P, P, P, P, Z],
     "pointops2_pairs_count_launcher": [I, P, P, P, P, P, P, P, P, Z],
@@ -88,6 +90,7 @@ RESULTS = {
     "pointops2_knn_workspace_bytes": ([I, I, I], Z),
     "pointops2_index_workspace_bytes": ([I], Z),
     "pointops2_partitions4_workspace_bytes": ([I], Z),
+    "pointops2_row_order_workspace_bytes": ([I], Z),
     "pointops2_cell_plan_workspace_bytes": ([I], Z),
 }
 

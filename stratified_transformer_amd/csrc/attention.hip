@@ -26,12 +26,13 @@ __global__ __launch_bounds__(256) void a1_fwd_kernel(int N, int h, const float *
                                                      const float *__restrict__ k,
                                                      const int *__restrict__ offs,
                                                      const int *__restrict__ idx1,
-                                                     float *__restrict__ attn) {
+                                                     float *__restrict__ attn, const int *__restrict__ rord) {
     constexpr int LPG = Geo<D>::LPG, PPW = Geo<D>::PPW;
     extern __shared__ float4 lds4[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + wave;
-    if (qi >= N) return;
+    const RowSlots slots(rord, N, 4, wave);
+    if (!slots.more()) return;
+    const int qi = slots.row();
     const int C = h * D, C4 = C / 4;
     float4 *qs = lds4 + wave * C4;
     for (int i = lane; i < C4; i += 64) qs[i] = ldg4(q + (size_t)qi * C + 4 * i);
@@ -75,11 +76,12 @@ __global__ __launch_bounds__(256) void gather_accum_kernel(int N, int h, const i
                                                            const int *__restrict__ widx,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ src,
-                                                           float *__restrict__ out) {
+                                                           float *__restrict__ out, const int *__restrict__ rord) {
     constexpr int LPG = Geo<D>::LPG, PPW = Geo<D>::PPW, HC = 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= N) return;
+    const RowSlots slots(rord, N, 4, wave);
+    if (!slots.more()) return;
+    const int row = slots.row();
     const int C = h * D;
     const int p = lane / LPG, c = lane % LPG;
     const int s = offs[row], e = offs[row + 1];
@@ -238,11 +240,12 @@ void attention_step1_forward_cuda_launcher_v2(int N, int M, int h, int C, const 
     (void)n_max;
     if (N <= 0 || M <= 0) return;
     hipStream_t st = state().stream;
-    const int blocks = div_up(N, 4);
+    const int *rord = rows_in_order(N);
+    const int blocks = rord ? ordered_grid(N, 4) : div_up(N, 4);
     const size_t lds = 4 * (size_t)C * sizeof(float);
     dispatch_d(C / h,
-               [&] { hipLaunchKernelGGL(a1_fwd_kernel<16>, dim3(blocks, N < 20000 ? div_up(h, 4) : 1), dim3(256), lds, st, N, h, q, k, index0_offsets, index1, attn); },
-               [&] { hipLaunchKernelGGL(a1_fwd_kernel<32>, dim3(blocks, N < 20000 ? div_up(h, 8) : 1), dim3(256), lds, st, N, h, q, k, index0_offsets, index1, attn); });
+               [&] { hipLaunchKernelGGL(a1_fwd_kernel<16>, dim3(blocks, N < 20000 ? div_up(h, 4) : 1), dim3(256), lds, st, N, h, q, k, index0_offsets, index1, attn, rord); },
+               [&] { hipLaunchKernelGGL(a1_fwd_kernel<32>, dim3(blocks, N < 20000 ? div_up(h, 8) : 1), dim3(256), lds, st, N, h, q, k, index0_offsets, index1, attn, rord); });
     check_launch();
 }
 
@@ -254,18 +257,20 @@ void attention_step1_backward_cuda_launcher_v2(int N, int M, int h, int C, const
     if (N <= 0 || M <= 0) return;
     hipStream_t st = state().stream;
     const LaunchState &ls = state();
-    const int blocks = div_up(N, 4);
+    const int *rord = rows_in_order(N);
+    const int blocks = rord ? ordered_grid(N, 4) : div_up(N, 4);
     const int *co = ls.csc_offsets, *cp = ls.csc_pair, *cq = ls.csc_query;
     ForkJoin fj(st, fork_worthwhile((int64_t)M * h));  // grad_q and grad_k are independent
     auto run = [&](auto dtag) {
         constexpr int D = decltype(dtag)::value;
         const int chunks = div_up(h, 4);
         hipLaunchKernelGGL((gather_accum_kernel<D, false>), dim3(blocks, chunks), dim3(256), 0, st, N, h, index0_offsets,
-                           index1, (const int *)nullptr, grad_out, k, grad_q);
+                           index1, (const int *)nullptr, grad_out, k, grad_q, rord);
         if (co) {
             const int NK = ls.key_rows > 0 ? ls.key_rows : N;
-            hipLaunchKernelGGL((gather_accum_kernel<D, true>), dim3(div_up(NK, 4), chunks), dim3(256), 0, fj.lane(1), NK, h, co, cq, cp,
-                               grad_out, q, grad_k);
+            const int *kord = rows_in_order(NK);  // (the keys of a window are its queries: the same order serves the transposed list)
+            hipLaunchKernelGGL((gather_accum_kernel<D, true>), dim3(kord ? ordered_grid(NK, 4) : div_up(NK, 4), chunks), dim3(256), 0, fj.lane(1), NK, h, co, cq, cp,
+                               grad_out, q, grad_k, kord);
         }
         else
             hipLaunchKernelGGL(scatter_atomic_kernel<D>, dim3(blocks), dim3(256), 0, st, N, h, index0_offsets,

@@ -19,6 +19,8 @@ struct LaunchState {
     int total_points = 0;  // pointops2_set_point_count: N of the next furthestsampling / knnquery call (0 = unknown)
     int batch_count = 0;   // pointops2_set_batch_count: b of the next knnquery call (0 = unknown)
     int key_rows = 0;      // pointops2_set_key_rows: rows of k / v when they differ from the CSR's query rows (0 = same)
+    const int *row_order = nullptr;  // pointops2_set_row_order: the rows in an order that keeps neighbours together (nullptr = by index)
+    int row_order_n = 0;             // ... and the row count it was built for
 };
 
 // scratch memory lent by the caller (pointops2_set_workspace), thread-local
@@ -128,10 +130,47 @@ inline void allow_big_lds(K kernel, size_t bytes) {
 }
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- rows in window order (pointops2_set_row_order) ----
+// The pair walkers give a wave a row (a query, or a key of the transposed list) and gather the rows of its partners: 64-byte head
+// rows of k / v / q / grad_out, and - by key - 12-byte snippets of the pair-indexed arrays.  In INDEX order neighbouring waves work
+// on unrelated windows and every gather goes to memory (the operator path moves 12x its compulsory bytes).  In an order
+// that keeps the rows of a window together (misc.hip, row_order_kernel: by the row's first partner, which is the lowest point id of
+// its window) the waves that run at one time share their partners and the second-level cache serves the gathers.  Workgroups are
+// handed to the eight XCDs in turn and every XCD has its own L2, so the order is cut into eight runs and workgroup b takes its slots
+// from run b % 8.
+inline const int *rows_in_order(int n_rows) {
+    const LaunchState &s = state();
+    return (s.row_order != nullptr && s.row_order_n == n_rows && n_rows >= 2048) ? s.row_order : nullptr;
+}
+// grid.x for a one-slot-per-wave launch (rows_per_wg waves): eight equal runs
+inline int ordered_grid(int n_rows, int rows_per_wg) { return 8 * div_up(div_up(n_rows, 8), rows_per_wg); }
 inline int64_t div_up64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- device helpers ----
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// the slots of one wave: by index (order == nullptr: slot = row, grid-strided) or along the eight runs of the row order
+struct RowSlots {
+    int pos, end, step;
+    const int *order;
+    __device__ __forceinline__ RowSlots(const int *order_, int n_rows, int waves_per_wg, int wave) : order(order_) {
+        if (order_ != nullptr && (gridDim.x & 7) == 0) {
+            const int per = (((n_rows + 7) >> 3) + waves_per_wg - 1) / waves_per_wg * waves_per_wg, run = blockIdx.x & 7;
+            pos = run * per + (blockIdx.x >> 3) * waves_per_wg + wave;
+            end = min((run + 1) * per, n_rows);
+            step = (gridDim.x >> 3) * waves_per_wg;
+        } else {
+            order = nullptr;
+            pos = blockIdx.x * waves_per_wg + wave;
+            end = n_rows;
+            step = gridDim.x * waves_per_wg;
+        }
+    }
+    __device__ __forceinline__ bool more() const { return pos < end; }
+    __device__ __forceinline__ int row() const { return order != nullptr ? order[pos] : pos; }
+    __device__ __forceinline__ void next() { pos += step; }
+};
 
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void stg4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }

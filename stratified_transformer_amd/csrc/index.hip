@@ -388,6 +388,22 @@ static size_t sort64_bytes(int N) {
                                              (const int *)nullptr, (int *)nullptr, N, 0, 64, (hipStream_t) nullptr);
     return bytes;
 }
+static size_t sort32_bytes(int N) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr, (const int *)nullptr, (int *)nullptr, N, 0, 32,
+                                             (hipStream_t) nullptr);
+    return bytes;
+}
+// key of a row in the window order: its first partner (the pair lists hold a window's own points first, ascending: the first partner
+// of every query of a window is the window's lowest point id); rows without partners go last
+__global__ void row_order_key_kernel(int N, int M, const int *__restrict__ offs, const int *__restrict__ idx1, unsigned *__restrict__ keys,
+                                     int *__restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int s = offs[i], e = offs[i + 1];
+    keys[i] = (s >= 0 && s < e && s < M) ? (unsigned)idx1[s] : 0xffffffffu;
+    vals[i] = i;
+}
 static size_t scan_bytes(int N) {
     size_t bytes = 0;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, bytes, (const int *)nullptr, (int *)nullptr, N, (hipStream_t) nullptr);
@@ -438,6 +454,29 @@ void pointops2_window_partition_launcher(int N, int b, const float *xyz, const i
     e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, N, st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
     hipLaunchKernelGGL(partition_finish_kernel, dim3(g), dim3(256), 0, st, N, order, flags, rank, cluster, starts, n_windows);
+    check_launch();
+}
+
+size_t pointops2_row_order_workspace_bytes(int N) {
+    if (N <= 0) return 0;
+    return 2 * al((size_t)N * 4) + al((size_t)N * 4) + al(sort32_bytes(N));
+}
+
+// order [N]: the rows of the CSR pair list (offsets [N+1], index1 [M]) sorted by their first partner, ties by row id - rows of one
+// window become neighbours (common.h, rows_in_order)
+void pointops2_row_order_launcher(int N, int M, const int *offsets, const int *index1, int *order, void *ws, size_t ws_bytes) {
+    if (N <= 0) return;
+    if (ws_bytes < pointops2_row_order_workspace_bytes(N)) { set_error("pointops2_row_order: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    char *p = reinterpret_cast<char *>(ws);
+    unsigned *keys_in = (unsigned *)p; p += al((size_t)N * 4);
+    unsigned *keys_out = (unsigned *)p; p += al((size_t)N * 4);
+    int *vals_in = (int *)p; p += al((size_t)N * 4);
+    size_t tmp_bytes = ws_bytes - (size_t)(p - reinterpret_cast<char *>(ws));
+    hipLaunchKernelGGL(row_order_key_kernel, dim3(div_up(N, 256)), dim3(256), 0, st, N, M, offsets, index1, keys_in, vals_in);
+    // (all 32 bits: rows without partners carry 0xffffffff)
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(p, tmp_bytes, (const unsigned *)keys_in, keys_out, (const int *)vals_in, order, N, 0, 32, st);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
     check_launch();
 }
 

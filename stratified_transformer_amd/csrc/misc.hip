@@ -247,6 +247,11 @@ void pointops2_set_table_rows(int L) { state().table_rows = L; }
 void pointops2_set_point_count(int N) { state().total_points = N; }
 void pointops2_set_batch_count(int b) { state().batch_count = b; }
 void pointops2_set_key_rows(int n) { state().key_rows = n; }
+void pointops2_set_row_order(const int *order, int n_rows) {
+    LaunchState &s = state();
+    s.row_order = order;
+    s.row_order_n = order != nullptr ? n_rows : 0;
+}
 void pointops2_set_csc(const int *csc_offsets, const int *csc_pair, const int *csc_query) {
     LaunchState &s = state();
     s.csc_offsets = csc_offsets;

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(768, 6) void a2_fwd_kernel(int N, int h, int L, con
                                                         const int *__restrict__ offs, const float *__restrict__ k,
                                                         const int *__restrict__ idx_k, const float *__restrict__ table_q,
                                                         const float *__restrict__ table_k, const int *__restrict__ rel,
-                                                        float *__restrict__ out) {
+                                                        float *__restrict__ out, const int *__restrict__ rord) {
     P2_WALK_PROLOGUE
     float *Tq = lds, *Tk = lds + tsz;
     stage_table<D>(Tq, table_q, L, h, h0, hgn);
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(768, 6) void a2_fwd_kernel(int N, int h, int L, con
     // group when h is not a multiple of HG) repeats that last head and its result is never stored.  With a branch
     // per head the compiler ends each head's block with a wait for its own key-row load, i.e. HG dependent memory
     // round trips per pass instead of one.
-    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
+    for (RowSlots slots(rord, N, wpb, wave); slots.more(); slots.next()) {
+        const int qi = slots.row();
         float4 q4[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++) q4[t] = ldg4(q + (size_t)qi * C + (h0 + min(t, hgn - 1)) * D + 4 * c);
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(768, 6) void wlogit_softmax_kernel(int N, int h, in
                                                                 const int *__restrict__ offs, const float *__restrict__ k,
                                                                 const int *__restrict__ idx_k, const float *__restrict__ table_q,
                                                                 const float *__restrict__ table_k, const int *__restrict__ rel,
-                                                                float *__restrict__ attn) {
+                                                                float *__restrict__ attn, const int *__restrict__ rord) {
     constexpr int D = 16;
     P2_WALK_PROLOGUE
     float *Tq = lds, *Tk = lds + tsz;
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(768, 6) void wlogit_softmax_kernel(int N, int h, in
         for (int st = LPG; st < 64; st <<= 1) v += __shfl_xor(v, st, 64);
         return v;
     };
-    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
+    for (RowSlots slots(rord, N, wpb, wave); slots.more(); slots.next()) {
+        const int qi = slots.row();
         float4 q4[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++)
@@ -315,13 +317,14 @@ template <int D, int HG>
 __global__ __launch_bounds__(512, 6) void a4_fwd_kernel(int N, int h, int L, const float *__restrict__ attn,
                                                         const float *__restrict__ v, const int *__restrict__ offs,
                                                         const int *__restrict__ idx1, const float *__restrict__ table,
-                                                        const int *__restrict__ rel, float *__restrict__ out) {
+                                                        const int *__restrict__ rel, float *__restrict__ out, const int *__restrict__ rord) {
     P2_WALK_PROLOGUE
     float *Tv = lds;
     stage_table<D>(Tv, table, L, h, h0, hgn);
     __syncthreads();
     const int wpb = blockDim.x >> 6;
-    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
+    for (RowSlots slots(rord, N, wpb, wave); slots.more(); slots.next()) {
+        const int qi = slots.row();
         float4 acc[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++) acc[t] = make_float4(0, 0, 0, 0);
@@ -416,11 +419,12 @@ template <int D>
 __global__ __launch_bounds__(256) void key_accum_kernel(int N, int h, const int *__restrict__ offs,
                                                         const int *__restrict__ sidx, const int *__restrict__ widx,
                                                         const float *__restrict__ w, const float *__restrict__ src,
-                                                        float *__restrict__ out) {
+                                                        float *__restrict__ out, const int *__restrict__ rord) {
     constexpr int LPG = Geo<D>::LPG, PPW = Geo<D>::PPW, HC = 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= N) return;
+    const RowSlots slots(rord, N, 4, wave);
+    if (!slots.more()) return;
+    const int row = slots.row();
     const int C = h * D;
     const int p = lane / LPG, c = lane % LPG;
     const int s = offs[row], e = offs[row + 1];
@@ -606,12 +610,12 @@ void dot_prod_with_idx_forward_cuda_launcher_v3(int N, int M, int h, int hdim, i
     if (hdim == 16) P2_LAUNCH_HG(16, 2, {
         allow_big_lds(a2_fwd_kernel<Dc, HGc>, lds_bytes);
         hipLaunchKernelGGL((a2_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 12, 2), ngroups), dim3(768), lds_bytes, st,
-                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output);
+                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output, rows_in_order(N));
     })
     else if (hdim == 32) P2_LAUNCH_HG(32, 2, {
         allow_big_lds(a2_fwd_kernel<Dc, HGc>, lds_bytes);
         hipLaunchKernelGGL((a2_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 12, 2), ngroups), dim3(768), lds_bytes, st,
-                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output);
+                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output, rows_in_order(N));
     })
     else { set_error("d != 16 and d != 32"); return; }
     check_launch();
@@ -628,7 +632,7 @@ void window_logits_softmax_forward_launcher(int N, int M, int h, int hdim, const
     P2_LAUNCH_HG(16, 2, {
         allow_big_lds(wlogit_softmax_kernel<HGc>, lds_bytes);
         hipLaunchKernelGGL((wlogit_softmax_kernel<HGc>), dim3(persistent_blocks(N, ngroups, 12, 2), ngroups), dim3(768), lds_bytes, st,
-                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, attn);
+                           N, h, L, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, attn, rows_in_order(N));
     })
     check_launch();
 }
@@ -717,12 +721,12 @@ void attention_step2_with_rel_pos_value_forward_cuda_launcher_v2(int N, int M, i
     if (hdim == 16) P2_LAUNCH_HG(16, 1, {
         allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
         hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 8, 3), ngroups), dim3(512), lds_bytes, st,
-                           N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output);
+                           N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output, rows_in_order(N));
     })
     else if (hdim == 32) P2_LAUNCH_HG(32, 1, {
         allow_big_lds(a4_fwd_kernel<Dc, HGc>, lds_bytes);
         hipLaunchKernelGGL((a4_fwd_kernel<Dc, HGc>), dim3(persistent_blocks(N, ngroups, 8, 3), ngroups), dim3(512), lds_bytes, st,
-                           N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output);
+                           N, h, L, attn, v, index0_offsets, index1, table, rel_idx, output, rows_in_order(N));
     })
     else { set_error("d != 16 and d != 32"); return; }
     check_launch();
@@ -747,7 +751,8 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
     const int NK4 = ls.key_rows > 0 ? ls.key_rows : N;
     if (co && hdim == 16 && L <= 80) {
         ForkJoin fj(st, fork_worthwhile((int64_t)M * h));  // grad_attn, grad_v and grad_table are independent
-        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(div_up(NK4, 4), div_up(h, 4)), dim3(256), 0, fj.lane(2), NK4, h, co, cq, cp, attn, grad_out, grad_v);
+        const int *kord = rows_in_order(NK4);
+        hipLaunchKernelGGL(key_accum_kernel<16>, dim3(kord ? ordered_grid(NK4, 4) : div_up(NK4, 4), div_up(h, 4)), dim3(256), 0, fj.lane(2), NK4, h, co, cq, cp, attn, grad_out, grad_v, kord);
         a4_bwd_mfma(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_table, fj);
         check_launch();
         return;
@@ -761,7 +766,7 @@ void attention_step2_with_rel_pos_value_backward_cuda_launcher_v2(int N, int M, 
                                lds_bytes, st, N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, \
                                grad_v, grad_table);                                                                         \
             hipLaunchKernelGGL(key_accum_kernel<Dc>, dim3(div_up(NK4, 4), div_up(h, 4)), dim3(256), 0, st, NK4, h, co, cq, cp, attn, grad_out, \
-                               grad_v);                                                                                     \
+                               grad_v, (const int *)nullptr);                                                                                     \
         } else {                                                                                                            \
             hipLaunchKernelGGL((a4_bwd_query_kernel<Dc, HGc, true>), dim3(persistent_blocks(N, ngroups), ngroups), dim3(256), \
                                lds_bytes, st, N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, \

@@ -53,14 +53,15 @@ template <int HG, bool ACCUM_OUT>
 __global__ __launch_bounds__(512, 8) void rows_table_sum_kernel(int N, int h, int L, const float *__restrict__ w,
                                                                 const int *__restrict__ offs, const int *__restrict__ pair_map,
                                                                 const float *__restrict__ table, const int *__restrict__ rel,
-                                                                float *__restrict__ grad_x) {
+                                                                float *__restrict__ grad_x, const int *__restrict__ rord) {
     constexpr int D = 16;
     P2_WALK_PROLOGUE
     float *T = lds;
     stage_table<D>(T, table, L, h, h0, hgn);
     __syncthreads();
     const int wpb = blockDim.x >> 6;
-    for (int row = blockIdx.x * wpb + wave; row < N; row += gridDim.x * wpb) {
+    for (RowSlots slots(rord, N, wpb, wave); slots.more(); slots.next()) {
+        const int row = slots.row();
         float4 acc[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++) acc[t] = make_float4(0, 0, 0, 0);
@@ -110,14 +111,15 @@ template <int HG>
 __global__ __launch_bounds__(512, 8) void a4_bwd_attn_kernel(int N, int h, int L, const float *__restrict__ go,
                                                              const int *__restrict__ offs, const int *__restrict__ idx1,
                                                              const float *__restrict__ v, const float *__restrict__ table,
-                                                             const int *__restrict__ rel, float *__restrict__ grad_attn) {
+                                                             const int *__restrict__ rel, float *__restrict__ grad_attn, const int *__restrict__ rord) {
     constexpr int D = 16;
     P2_WALK_PROLOGUE
     float *T = lds;
     stage_table<D>(T, table, L, h, h0, hgn);
     __syncthreads();
     const int wpb = blockDim.x >> 6;
-    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
+    for (RowSlots slots(rord, N, wpb, wave); slots.more(); slots.next()) {
+        const int qi = slots.row();
         float4 g4[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++)
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
                                                                       const float *__restrict__ X, const int *__restrict__ offs,
                                                                       const int *__restrict__ pair_map, const int *__restrict__ rel,
                                                                       float *__restrict__ grad_table,
-                                                                      unsigned long long *__restrict__ dbg = nullptr) {
+                                                                      const int *__restrict__ rord, unsigned long long *__restrict__ dbg = nullptr) {
     unsigned long long c_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
     auto stamp = [&](int ph) {  // everything issued so far has completed; the time since the last stamp goes to phase ph
         if (STAMP) {
@@ -240,7 +242,9 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
     // is shared by several times more queries than an ordinary one - and every group ends in a barrier.
     __shared__ int next_row;
     const int per = (N + gridDim.x - 1) / gridDim.x;
-    const int rb = min(N, (int)blockIdx.x * per), re = min(N, rb + per);
+    // (rows in window order, common.h: the shares are runs of the order, consecutive runs on one XCD)
+    const int share = (rord != nullptr && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int rb = min(N, share * per), re = min(N, rb + per);
     if (threadIdx.x == 0) next_row = rb;
     __syncthreads();
     stamp(0);  // 0: prologue (zeroing the histograms)
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(TG_WAVES * 64, 6) void table_grad_kernel(int N, int
         int r = 0;
         if (lane == 0) r = atomicAdd(&next_row, 1);
         r = __builtin_amdgcn_readfirstlane(r);
-        return r < re ? r : -1;
+        return r < re ? (rord != nullptr ? rord[r] : r) : -1;
     };
     int row = -1, cur = 0, end = 0;
     int nrow = claim(), ncur = 0, nend = 0;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(512, 4) void wattn_bwd_query_kernel(int N, int h, i
                                                                  const float *__restrict__ attn, const float *__restrict__ v,
                                                                  const float *__restrict__ k, const float *__restrict__ table_v,
                                                                  const float *__restrict__ table_q, const int *__restrict__ rel,
-                                                                 float *__restrict__ grad_logit, float *__restrict__ grad_q) {
+                                                                 float *__restrict__ grad_logit, float *__restrict__ grad_q, const int *__restrict__ rord) {
     constexpr int D = 16;
     P2_WALK_PROLOGUE
     float *Tv = lds, *Tq = lds + tsz;
@@ -426,7 +430,8 @@ __global__ __launch_bounds__(512, 4) void wattn_bwd_query_kernel(int N, int h, i
         return x;
     };
     const bool mine = c < hgn;
-    for (int qi = blockIdx.x * wpb + wave; qi < N; qi += gridDim.x * wpb) {
+    for (RowSlots slots(rord, N, wpb, wave); slots.more(); slots.next()) {
+        const int qi = slots.row();
         float4 g4[HG], acc1[HG], acc2[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++) {
@@ -529,14 +534,15 @@ __global__ __launch_bounds__(512, 4) void wattn_bwd_key_kernel(int NK, int h, in
                                                                const float *__restrict__ q, const int *__restrict__ csc_offs,
                                                                const int *__restrict__ csc_pair, const int *__restrict__ csc_query,
                                                                const float *__restrict__ table_k, const int *__restrict__ rel,
-                                                               float *__restrict__ grad_k, float *__restrict__ grad_v) {
+                                                               float *__restrict__ grad_k, float *__restrict__ grad_v, const int *__restrict__ rord) {
     constexpr int D = 16;
     P2_WALK_PROLOGUE
     float *Tk = lds;
     stage_table<D>(Tk, table_k, L, h, h0, hgn);
     __syncthreads();
     const int wpb = blockDim.x >> 6;
-    for (int kj = blockIdx.x * wpb + wave; kj < NK; kj += gridDim.x * wpb) {
+    for (RowSlots slots(rord, NK, wpb, wave); slots.more(); slots.next()) {
+        const int kj = slots.row();
         float4 a1[HG], a2[HG], av[HG];
 #pragma unroll
         for (int t = 0; t < HG; t++) a1[t] = a2[t] = av[t] = make_float4(0, 0, 0, 0);
@@ -607,7 +613,7 @@ static void launch_table_grad(int N, int h, int L, const float *w, const float *
             (void)hipMemset(dbg, 0, sizeof(host));
             const int bx = walk_blocks(N, groups, TG_WAVES, 2);
             hipLaunchKernelGGL((table_grad_kernel<HG, TA, true>), dim3(bx, groups), dim3(TG_WAVES * 64), lds, st, N, h, L, w, X, offs,
-                               pair_map, rel, grad_table, dbg);
+                               pair_map, rel, grad_table, rows_in_order(N), dbg);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
             (void)hipFree(dbg);
@@ -619,7 +625,7 @@ static void launch_table_grad(int N, int h, int L, const float *w, const float *
             return;
         }
         hipLaunchKernelGGL((table_grad_kernel<HG, TA>), dim3(walk_blocks(N, groups, TG_WAVES, 2), groups), dim3(TG_WAVES * 64), lds, st,
-                           N, h, L, w, X, offs, pair_map, rel, grad_table);
+                           N, h, L, w, X, offs, pair_map, rel, grad_table, rows_in_order(N));
     });
 }
 
@@ -634,9 +640,9 @@ bool a2_bwd_mfma(int N, int NK, int M, int h, int hdim, int L, const float *go, 
         const int groups = div_up(h, HG);
         const size_t lds = (size_t)HG * 3 * L * 16 * sizeof(float);
         hipLaunchKernelGGL((rows_table_sum_kernel<HG, true>), dim3(walk_blocks(NK, groups, 8, 4), groups), dim3(512), lds, fj.lane(0),
-                           NK, h, L, go, co, cp, table_k, rel, grad_k);
+                           NK, h, L, go, co, cp, table_k, rel, grad_k, rows_in_order(NK));
         hipLaunchKernelGGL((rows_table_sum_kernel<HG, false>), dim3(walk_blocks(N, groups, 8, 4), groups), dim3(512), lds, fj.lane(1),
-                           N, h, L, go, offs, (const int *)nullptr, table_q, rel, grad_q);
+                           N, h, L, go, offs, (const int *)nullptr, table_q, rel, grad_q, rows_in_order(N));
     });
     if (L <= 64) {
         launch_table_grad<4>(NK, h, L, go, k, co, cp, rel, gtk, fj.lane(2));
@@ -656,7 +662,7 @@ bool a4_bwd_mfma(int N, int h, int hdim, int L, const float *go, const int *offs
         const int groups = div_up(h, HG);
         const size_t lds = (size_t)HG * 3 * L * 16 * sizeof(float);
         hipLaunchKernelGGL((a4_bwd_attn_kernel<HG>), dim3(walk_blocks(N, groups, 8, 4), groups), dim3(512), lds, fj.lane(0),
-                           N, h, L, go, offs, idx1, v, table, rel, grad_attn);
+                           N, h, L, go, offs, idx1, v, table, rel, grad_attn, rows_in_order(N));
     });
     if (L <= 64) launch_table_grad<4>(N, h, L, attn, go, offs, nullptr, rel, grad_table, fj.lane(1));
     else launch_table_grad<5>(N, h, L, attn, go, offs, nullptr, rel, grad_table, fj.lane(1));
@@ -676,7 +682,7 @@ bool wattn_bwd(int N, int NK, int M, int h, int hdim, int L, const float *go, co
         const size_t lds2 = (size_t)2 * HG * 3 * L * 16 * sizeof(float);
         allow_big_lds(wattn_bwd_query_kernel<HG>, lds2);
         hipLaunchKernelGGL((wattn_bwd_query_kernel<HG>), dim3(walk_blocks(N, groups, 8, 2), groups), dim3(512), lds2, st,
-                           N, h, L, go, offs, idx1, attn, v, k, table_v, table_q, rel, grad_logit, grad_q);
+                           N, h, L, go, offs, idx1, attn, v, k, table_v, table_q, rel, grad_logit, grad_q, rows_in_order(N));
     });
     // everything below only reads grad_logit: the key walk and the three table gradients are independent
     ForkJoin fj(st, fork_worthwhile((int64_t)M * h));
@@ -685,7 +691,7 @@ bool wattn_bwd(int N, int NK, int M, int h, int hdim, int L, const float *go, co
         const int groups = div_up(h, HG);
         const size_t lds1 = (size_t)HG * 3 * L * 16 * sizeof(float);
         hipLaunchKernelGGL((wattn_bwd_key_kernel<HG>), dim3(walk_blocks(NK, groups, 8, 2), groups), dim3(512), lds1, fj.lane(0),
-                           NK, h, L, grad_logit, attn, go, q, co, cp, cq, table_k, rel, grad_k, grad_v);
+                           NK, h, L, grad_logit, attn, go, q, co, cp, cq, table_k, rel, grad_k, grad_v, rows_in_order(NK));
     });
     if (L <= 64) {
         launch_table_grad<4>(NK, h, L, grad_logit, k, co, cp, rel, gtk, fj.lane(1));

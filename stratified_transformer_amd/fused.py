@@ -43,10 +43,11 @@ class WindowAttention(Function):
                            (index0_offsets, torch.int32, "index0_offsets"), (index1, torch.int32, "index1"), (rel_idx, torch.int32, "rel_idx"))
         attn = torch.empty((M, h), dtype=torch.float32, device=q.device)
         pointops_cuda._rows(table_q)
-        pointops_cuda._call("window_logits_softmax_forward_launcher", q, int(index0_offsets.shape[0]) - 1, M, h, hdim,
-                            ptr(q), ptr(index0_offsets), ptr(k), ptr(index1), ptr(table_q), ptr(table_k), ptr(rel_idx), ptr(attn))
         out = torch.zeros((N, h, hdim), dtype=torch.float32, device=q.device)
-        pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, 0, attn, v, index0_offsets, index1, table_v, rel_idx, out)
+        with P._with_rows(P.row_order_of(index0_offsets, index1)):  # (the pair walkers take their rows in window order, csrc/common.h)
+            pointops_cuda._call("window_logits_softmax_forward_launcher", q, int(index0_offsets.shape[0]) - 1, M, h, hdim,
+                                ptr(q), ptr(index0_offsets), ptr(k), ptr(index1), ptr(table_q), ptr(table_k), ptr(rel_idx), ptr(attn))
+            pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, 0, attn, v, index0_offsets, index1, table_v, rel_idx, out)
         ctx.save_for_backward(q, k, v, table_q, table_k, table_v, index0_offsets, index1, rel_idx, attn)
         return out
 
@@ -68,12 +69,12 @@ class WindowAttention(Function):
             grad_tq, grad_tk, grad_tv = z(L, h, hdim, 3), z(L, h, hdim, 3), z(L, h, hdim, 3)
             pointops_cuda._chk((grad_out, torch.float32, "grad_out"))
             pointops_cuda._rows(table_q)
-            with P._with_csc(csc):
+            with P._with_csc(csc), P._with_rows(P.row_order_of(offs, index1)):
                 pointops_cuda._call("window_attention_backward_launcher", q, int(offs.shape[0]) - 1, M, h, hdim, ptr(grad_out), ptr(q), ptr(k),
                                     ptr(v), ptr(attn), ptr(offs), ptr(index1), ptr(table_q), ptr(table_k), ptr(table_v), ptr(rel_idx),
                                     ptr(grad_logit), ptr(grad_q), ptr(grad_k), ptr(grad_v), ptr(grad_tq), ptr(grad_tk), ptr(grad_tv))
             return grad_q, grad_k, grad_v, grad_tq, grad_tk, grad_tv, None, None, None
-        with P._with_csc(csc):
+        with P._with_csc(csc), P._with_rows(P.row_order_of(offs, index1)):
             # the operators' own backward launchers, in autograd's order
             grad_attn = e(M, h)
             grad_v, grad_tv = z(v.shape[0], h, hdim), z(L, h, hdim, 3)

@@ -401,6 +401,10 @@ def _stage_index_hip(ctx, xyz, offset, quant_size, downsample_idx, cell_table_ro
                     plan = CellPlan(N, n_cells, P, K, nk_max, int(cell_table_rows), n_parents, cell_keys=cell_keys, kcell=kcell, relp=relp,
                                     max_queries=int(cell_max_queries), **cells)
                 out[which] = BlockIndex(index_0, index_1, offsets, counts.max(), rel, None, plan, parts=parts)
+                # the small-window partition's point order groups the rows of the pair list by window: the operators' pair walkers
+                # take their rows in it (pointops.row_order_of) without sorting anything
+                from . import pointops as _P
+                _P.seed_row_order(offsets, index_1, s.order, out[which].n_max)
                 fills.append((s, lg, ls, ls_starts, wc, offsets, index_0, index_1, rel))
             if cell_table_rows is not None:
                 ev = torch.cuda.Event()

@@ -15,6 +15,7 @@ Differences, all compatible:
     key-side gradients are gathered.
   * Inputs must be GPU tensors: there is no CPU fallback.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -160,9 +161,81 @@ def csr_matches(offsets, index):
     return bad[0] == 0
 
 
+_ROW_ORDER_CACHE = OrderedDict()
+_ROW_ORDER_CACHE_SIZE = 16
+ROW_ORDER = os.environ.get("P2_ROW_ORDER", "1") != "0"
+ROW_ORDER_BUILDS = 0
+
+
+def row_order_of(index0_offsets, index1, alias=None):
+    """The rows of the pair list in window order (csrc/index.hip pointops2_row_order_launcher: sorted by their first partner), cached
+    like the CSC by the identity (address + version) of the two index tensors - or of `alias`, the block's n_max tensor (csc_of);
+    None when it is not worth having (small clouds) or switched off (P2_ROW_ORDER=0).  The operators' pair walkers take their rows
+    in this order (csrc/common.h rows_in_order): same sums, neighbouring waves share their partners' rows in the second-level cache."""
+    N = int(index0_offsets.shape[0]) - 1
+    if not ROW_ORDER or N < 2048 or not index1.is_cuda:
+        return None
+    akey = None
+    if torch.is_tensor(alias):
+        akey = ("n_max", alias.data_ptr(), alias._version, int(index1.shape[0]), N, index1.device.index)
+        hit = _ROW_ORDER_CACHE.get(akey)
+        if hit is not None:
+            _ROW_ORDER_CACHE.move_to_end(akey)
+            return hit[0]
+    key = (index0_offsets.data_ptr(), index0_offsets._version, index1.data_ptr(), index1._version, int(index1.shape[0]), N, index1.device.index)
+    hit = _ROW_ORDER_CACHE.get(key)
+    if hit is not None:
+        _ROW_ORDER_CACHE.move_to_end(key)
+        if akey is not None:
+            _ROW_ORDER_CACHE[akey] = hit
+        return hit[0]
+    l = _lib.lib()
+    order = torch.empty(N, dtype=torch.int32, device=index1.device)
+    ws = torch.empty(int(l.pointops2_row_order_workspace_bytes(N)), dtype=torch.uint8, device=index1.device)
+    _lib.call("pointops2_row_order_launcher", N, int(index1.shape[0]), ptr(index0_offsets), ptr(index1), ptr(order), ptr(ws), ws.numel(), device=index1.device)
+    _ROW_ORDER_CACHE[key] = (order, index0_offsets, index1, alias)   # (the entry keeps the tensors alive: their addresses cannot be recycled)
+    if akey is not None:
+        _ROW_ORDER_CACHE[akey] = _ROW_ORDER_CACHE[key]
+    global ROW_ORDER_BUILDS
+    ROW_ORDER_BUILDS += 1
+    while len(_ROW_ORDER_CACHE) > _ROW_ORDER_CACHE_SIZE:
+        _ROW_ORDER_CACHE.popitem(last=False)
+    return order
+
+
+def seed_row_order(index0_offsets, index1, order, alias=None):
+    """A caller that already has the rows of the pair list grouped by window (index_build.stage_index_hip: the small-window
+    partition's point order IS such an order) hands it over; row_order_of then finds it instead of sorting."""
+    N = int(index0_offsets.shape[0]) - 1
+    if not ROW_ORDER or N < 2048 or order is None or int(order.shape[0]) != N:
+        return
+    entry = (order, index0_offsets, index1, alias)
+    _ROW_ORDER_CACHE[(index0_offsets.data_ptr(), index0_offsets._version, index1.data_ptr(), index1._version, int(index1.shape[0]), N, index1.device.index)] = entry
+    if torch.is_tensor(alias):
+        _ROW_ORDER_CACHE[("n_max", alias.data_ptr(), alias._version, int(index1.shape[0]), N, index1.device.index)] = entry
+    while len(_ROW_ORDER_CACHE) > _ROW_ORDER_CACHE_SIZE:
+        _ROW_ORDER_CACHE.popitem(last=False)
+
+
+class _with_rows:
+    """the pair walkers of the launchers called inside take their rows in `order` (None: by index)"""
+
+    def __init__(self, order):
+        self.order = order
+
+    def __enter__(self):
+        if self.order is not None:
+            _lib.lib().pointops2_set_row_order(ptr(self.order), int(self.order.shape[0]))
+
+    def __exit__(self, *exc):
+        if self.order is not None:
+            _lib.lib().pointops2_set_row_order(None, 0)
+
+
 def clear_caches():
     _LAST_CSR.clear()
     _CSC_CACHE.clear()
+    _ROW_ORDER_CACHE.clear()
     _FPS_CACHE.clear()
     _HOST_OFFSETS.clear()
 
@@ -391,7 +464,8 @@ class AttentionStep1_v2(Function):
         output = torch.empty((M, h), dtype=torch.float32, device=q.device)
         # the launcher's N is the number of CSR rows (queries); the reference passes N_k, which is the same
         # number in the model and would be wrong anywhere else (its kernel grid is one block per query)
-        pointops_cuda.attention_step1_forward_cuda_v2(int(index0_offsets.shape[0]) - 1, M, h, C, _nmax(n_max), q, k, index0_offsets, index1, output)
+        with _with_rows(row_order_of(index0_offsets, index1, n_max)):
+            pointops_cuda.attention_step1_forward_cuda_v2(int(index0_offsets.shape[0]) - 1, M, h, C, _nmax(n_max), q, k, index0_offsets, index1, output)
         remember_csr(index0_offsets, M)
         ctx.N_q, ctx.N_k, ctx.C, ctx.n_max = N_q, N_k, C, n_max
         ctx.save_for_backward(q, k, index0_offsets, index1)
@@ -406,7 +480,7 @@ class AttentionStep1_v2(Function):
         grad_output = grad_output.contiguous()
         grad_q = torch.empty((N_q, h, C // h), dtype=torch.float32, device=q.device)
         grad_k = _zeros((N_k, h, C // h), q)
-        with _with_csc(csc_of(index0_offsets, index1, N_k, ctx.n_max)):
+        with _with_csc(csc_of(index0_offsets, index1, N_k, ctx.n_max)), _with_rows(row_order_of(index0_offsets, index1, ctx.n_max)):
             pointops_cuda.attention_step1_backward_cuda_v2(int(index0_offsets.shape[0]) - 1, M, h, C, _nmax(ctx.n_max), grad_output, index0_offsets, index1, q, k, grad_q, grad_k)
         return grad_q, grad_k, None, None, None
 
@@ -540,7 +614,8 @@ class DotProdWithIdx_v3(Function):
         assert table_k.shape[0] == L
         _check_pair_list("dot_prod_with_idx_v3", N, index_q_offsets, index_k, rel_idx)
         output = torch.empty((M, h), dtype=torch.float32, device=q.device)
-        pointops_cuda.dot_prod_with_idx_forward_cuda_v3(N, M, h, hdim, _nmax(n_max), q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output)
+        with _with_rows(row_order_of(index_q_offsets, index_k, n_max)):
+            pointops_cuda.dot_prod_with_idx_forward_cuda_v3(N, M, h, hdim, _nmax(n_max), q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output)
         remember_csr(index_q_offsets, M)
         ctx.n_max = n_max
         ctx.save_for_backward(q, index_q_offsets, k, index_k, table_q, table_k, rel_idx)
@@ -557,7 +632,7 @@ class DotProdWithIdx_v3(Function):
         grad_q = torch.empty((N, h, hdim), dtype=torch.float32, device=q.device)
         grad_k = _zeros((k.shape[0], h, hdim), q)
         grad_table_q, grad_table_k = _zeros((L, h, hdim, 3), q), _zeros((L, h, hdim, 3), q)
-        with _with_csc(csc_of(index_q_offsets, index_k, k.shape[0], ctx.n_max)):
+        with _with_csc(csc_of(index_q_offsets, index_k, k.shape[0], ctx.n_max)), _with_rows(row_order_of(index_q_offsets, index_k, ctx.n_max)):
             pointops_cuda.dot_prod_with_idx_backward_cuda_v3(N, M, h, hdim, _nmax(ctx.n_max), grad_output, q, index_q_offsets, k, index_k,
                                                              table_q, table_k, rel_idx, grad_q, grad_k, grad_table_q, grad_table_k)
         return grad_q, None, None, grad_k, None, grad_table_q, grad_table_k, None
@@ -609,7 +684,8 @@ class AttentionStep2WithRelPosValue_v2(Function):
         N = int(index0_offsets.shape[0]) - 1  # CSR rows = queries (== N_v in the model, :594-597)
         _check_pair_list("attention_step2_with_rel_pos_value_v2", N, index0_offsets, index1, rel_idx, attn)
         output = torch.empty((N, h, hdim), dtype=torch.float32, device=v.device)
-        pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, _nmax(n_max), attn, v, index0_offsets, index1, table, rel_idx, output)
+        with _with_rows(row_order_of(index0_offsets, index1, n_max)):
+            pointops_cuda.attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, _nmax(n_max), attn, v, index0_offsets, index1, table, rel_idx, output)
         ctx.n_max = n_max
         ctx.save_for_backward(attn, v, index0_offsets, index1, table, rel_idx)
         return output
@@ -624,7 +700,7 @@ class AttentionStep2WithRelPosValue_v2(Function):
         assert grad_output.is_contiguous()
         grad_attn = torch.empty((M, h), dtype=torch.float32, device=v.device)
         grad_v, grad_table = _zeros((N_v, h, hdim), v), _zeros((L, h, hdim, 3), v)
-        with _with_csc(csc_of(index0_offsets, index1, N_v, ctx.n_max)):
+        with _with_csc(csc_of(index0_offsets, index1, N_v, ctx.n_max)), _with_rows(row_order_of(index0_offsets, index1, ctx.n_max)):
             pointops_cuda.attention_step2_with_rel_pos_value_backward_cuda_v2(N, M, h, hdim, _nmax(ctx.n_max), grad_output, index0_offsets, index1,
                                                                               attn, v, table, rel_idx, grad_attn, grad_v, grad_table)
         return grad_attn, grad_v, None, None, None, grad_table, None

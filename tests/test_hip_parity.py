@@ -638,6 +638,59 @@ def test_index_build_of_a_scene_wider_than_the_fixed_key():
             assert np.array_equal(_np(getattr(blk, field)), want[field].numpy()), (par, field)
 
 
+def test_operators_with_rows_in_window_order_equal_rows_by_index(P):
+    """The operators' pair walkers take their rows in window order (pointops.row_order_of / pointops2_set_row_order: neighbouring
+    waves share their partners' rows in L2) - the sums of a row do not change: logits, softmax, output and the row gradients are
+    bit-identical to the walk by index, the table gradients (float atomics) to 1e-5.  Also: the order is a permutation that keeps
+    the rows of a window together, and it is built once per pair list (three forward + three backward operators: one build)."""
+    from stratified_transformer_amd import index_build, scene
+    n, w, quant, h = 9000, 0.16, 0.01, 3
+    xyz_np, offset = scene.make_batch([5000, 4000], seed=31)
+    xyz, off = dev(xyz_np), dev(offset)
+    ds = P.furthestsampling(xyz, off, dev(np.array(index_build.stratified_new_offset(offset.tolist(), 8), np.int32)))
+    even, _, _ = index_build.stage_index_hip(xyz, off, w, quant, ds)
+    g = torch.Generator().manual_seed(4)
+    L = 2 * int((2 * w + 1e-4) // quant)
+    leaves = [torch.randn(n, h, 16, generator=g).cuda().requires_grad_(True) for _ in range(3)] + \
+             [(0.3 * torch.randn(L, h, 16, 3, generator=g)).cuda().requires_grad_(True) for _ in range(3)]
+    go = torch.randn(n, h, 16, generator=g).cuda()
+
+    def run():
+        q, k, v, tq, tk, tv = leaves
+        for t in leaves:
+            t.grad = None
+        a = P.attention_step1_v2(q, k, even.index_1, even.offsets, even.n_max) + \
+            P.dot_prod_with_idx_v3(q, even.offsets, even.n_max, k, even.index_1, tq, tk, even.rel_idx)
+        sm = P.segment_softmax(a, even.offsets)
+        out = P.attention_step2_with_rel_pos_value_v2(sm, v, even.offsets, even.n_max, even.index_1, tv, even.rel_idx)
+        out.backward(go)
+        torch.cuda.synchronize()
+        return [a.detach().clone(), out.detach().clone()] + [t.grad.clone() for t in leaves]
+
+    was = P.ROW_ORDER
+    try:
+        P.ROW_ORDER = False
+        P.clear_caches()
+        by_index = run()
+        P.ROW_ORDER = True
+        builds = P.ROW_ORDER_BUILDS
+        in_order = run()
+        assert P.ROW_ORDER_BUILDS == builds + 1
+        order = P.row_order_of(even.offsets, even.index_1, even.n_max)
+    finally:
+        P.ROW_ORDER = was
+    names = ["logits", "out", "grad_q", "grad_k", "grad_v", "grad_tq", "grad_tk", "grad_tv"]
+    for name, a, b in zip(names, by_index, in_order):
+        if name.startswith("grad_t"):
+            torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-5 * max(float(a.abs().max()), 1.0), msg=name)
+        else:
+            assert torch.equal(a, b), name
+    o = _np(order)
+    assert np.array_equal(np.sort(o), np.arange(n))
+    first = _np(even.index_1)[_np(even.offsets)[:-1]][o]               # first partner of every row, in the order
+    assert np.all(np.diff(first.astype(np.int64)) >= 0)                # = sorted by window (its lowest point id)
+
+
 def test_query_shard_ops_with_more_keys_than_queries(P):
     """What a rank of a sharded scene runs: CSR rows = its own queries, k/v rows = all points.  The rows
     of the sharded results equal the unsharded ones; key-side gradients sum over shards to the full ones."""

@@ -14,7 +14,12 @@ def main():
     stages = [int(s) for s in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 1, 2, 3]
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     cfg = pipeline.s3dis_config()
-    xyz = torch.from_numpy(scene.make_room(N, 0)).cuda()
+    xyz_np = scene.make_room(N, 0)
+    if os.environ.get('SORTED'):  # experiment: points in (large) window order - what memory locality of the rows would give
+        import numpy as np
+        c = np.floor(xyz_np / float(os.environ['SORTED'])).astype(np.int64)
+        xyz_np = np.ascontiguousarray(xyz_np[np.argsort((c[:, 2] * 4096 + c[:, 1]) * 4096 + c[:, 0], kind='stable')])
+    xyz = torch.from_numpy(xyz_np).cuda()
     off = torch.tensor([N], dtype=torch.int32, device='cuda')
     states, results = pipeline.scene_pass(xyz, off, cfg, cells=True)
     torch.cuda.synchronize()

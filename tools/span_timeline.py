@@ -1,5 +1,6 @@
 """Un-profiled timeline of one scene pass from the pipeline's own event spans (diagnostic; GPU box only)."""
 import os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # as bench.py
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stratified_transformer_amd import scene, pipeline

@@ -532,8 +532,8 @@ def cpu_baseline(run):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=IN_FLIGHT_DEFAULT, help="batches in flight of the in_flight leg (fixed; 1 = skip the leg)")
     ap.add_argument("--shard", action="store_true", help="N > 1: ONE scene sharded over the ranks (SURVEY 8e) instead of one scene per rank")

@@ -51,6 +51,7 @@ CHAIN = os.environ.get("P2_LAYER_CHAIN", "1") != "0"
 SPECULATE = os.environ.get("P2_SPECULATE", "1") != "0"
 STATS = {"layers": 0, "speculated": 0, "reruns": 0, "transitions_prefetched": 0}
 _CLOUDS = {}  # id(xyz) -> _Cloud
+_FLAG_HOST = {}  # device index -> ring of pinned bool [1] words (speculation checks)
 
 
 class _Cloud:
@@ -257,7 +258,11 @@ def basic_layer_forward(self, feats, xyz, offset):
     if checks:
         STATS["speculated"] += 1
         with torch.cuda.stream(geo):
-            wrong = torch.stack(checks).any().to("cpu", non_blocking=True)
+            wrong = _FLAG_HOST.get(dev.index)
+            if wrong is None:  # (one pinned word per device, reused: a fresh pinned allocation per layer costs milliseconds now and then)
+                wrong = _FLAG_HOST[dev.index] = [torch.empty(1, dtype=torch.bool, pin_memory=True) for _ in range(8)]
+            wrong = wrong[STATS["speculated"] % 8]  # (a ring: the previous layers' words may not have been read yet)
+            wrong.copy_(torch.stack(checks).any().reshape(1), non_blocking=True)
             seen = torch.cuda.Event()
             seen.record(geo)
 

@@ -319,6 +319,7 @@ class _IndexBuilder:
             raise self._error
 
 
+_FLAG_HOST = {}  # (device index, lane) -> pinned bool [1]: the speculation check of a pass arrives here
 _RETIRED = {}  # (device index, lane) -> deque of (event on the lane's main stream at the end of a pass, tensors kept alive until then)
 
 
@@ -686,7 +687,11 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
     timer.run("mark/streams_joined", lambda: None)
     if checks:
         with on_geo():
-            wrong = torch.stack(checks).any().to("cpu", non_blocking=True)  # (pinned staging by the allocator; complete at the event)
+            # (one pinned word per lane, reused: a fresh pinned allocation per pass showed as 3-5 ms outliers, tools/pass_times.py)
+            wrong = _FLAG_HOST.get((dev.index, lane))
+            if wrong is None:
+                wrong = _FLAG_HOST[(dev.index, lane)] = torch.empty(1, dtype=torch.bool, pin_memory=True)
+            wrong.copy_(torch.stack(checks).any().reshape(1), non_blocking=True)
             seen = torch.cuda.Event()
             seen.record(geo)
         keep.extend(checks)

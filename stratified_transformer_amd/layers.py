@@ -92,8 +92,24 @@ def _prefix(off_host, new_off_host, dev):
     return torch.cat([torch.arange(s_, s_ + c_, dtype=torch.int32, device=dev) for s_, c_ in zip(starts, counts)])
 
 
+_STAGING = {}  # device index -> [pinned int32 ring [slots, width], next slot]
+
+
 def _offsets(values, dev):
-    t = torch.tensor(values, dtype=torch.int32, device=dev)
+    """Offsets known on the host -> device tensor, without stopping the host: torch.tensor(..., device=) copies from pageable memory
+    (~0.3 ms of host time each, tools/host_profile_layers.py); a slot of a small pinned ring + a non-blocking copy does not.  A slot is
+    written again 64 uploads later - several forward passes, each of which reads results back (the index build) after its uploads."""
+    n = len(values)
+    if n > 64:
+        t = torch.tensor(values, dtype=torch.int32, device=dev)
+    else:
+        ring = _STAGING.get(dev.index)
+        if ring is None:
+            ring = _STAGING[dev.index] = [torch.empty((64, 64), dtype=torch.int32, pin_memory=True), 0]
+        slot = ring[0][ring[1] % 64]
+        ring[1] += 1
+        slot[:n] = torch.tensor(values, dtype=torch.int32)
+        t = slot[:n].to(dev, non_blocking=True)
     P.hint_host_offsets(t, values)
     return t
 

@@ -28,6 +28,8 @@ def main():
         tq, tk, tv = s.tables
         for pat in ('even', 'odd'):
             plan = r[pat].cells
+            if os.environ.get('TASKS') == 'natural':  # experiment: cells in their (small window, large window) order instead of by size
+                plan = plan.with_tasks(torch.arange(plan.n_cells, dtype=torch.int32, device='cuda'), torch.tensor([plan.n_cells], dtype=torch.int32, device='cuda'))
             for x in (s.q, s.k, s.v, tq, tk, tv):
                 x.grad = None
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

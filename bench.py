@@ -157,6 +157,8 @@ def run_gpu(args, rank, world):
             from stratified_transformer_amd import sharding
             sharding.reset_bytes()
         barrier()
+        from stratified_transformer_amd import _lib as _l
+        calls0, allocs0 = _l.CALLS[0], torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
         with no_gc():
             t0 = time.perf_counter()
             for _ in range(args.steps):
@@ -165,6 +167,8 @@ def run_gpu(args, rank, world):
             elapsed = max_over_ranks(time.perf_counter() - t0)
         states = st
         leg = dict(elapsed=elapsed, live=live, results=summary(res))
+        leg["host"] = dict(library_calls_per_pass=round((_l.CALLS[0] - calls0) / args.steps, 1),
+                           torch_allocations_per_pass=round((torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0) - allocs0) / args.steps, 1))
         if shard:
             leg["bytes_moved"] = sharding.BYTES_MOVED
             leg["halo_fraction"] = [r.get("halo_fraction") for r in res]
@@ -572,6 +576,9 @@ def main():
                               "samples taken as the identity prefix while the sampler verifies them; a training loop that calls the package's pass, not the "
                               "unmodified model file (that one: cell_model_order)")
         cell["speculation"] = run.get("speculation")
+        cell["host"] = dict(run["single_cell"]["host"], note="launcher calls of the library (each a handful of kernel launches: ~900 kernels per pass, "
+                            "profiles/r03_c_kernel_stats.csv) and caching-allocator allocations per pass; VERDICT r2 #5 asked for <= 120 launches and <= 20 allocations")
+        ops["host"] = run["single_ops"]["host"]
         ops["reached_by"] = ("the five operators of the drop-in pointops API on a pair list built once per stage (index_build.stage_index_hip): a caller that "
                              "owns its BasicLayer but keeps the reference's operators")
         extra_legs = {}

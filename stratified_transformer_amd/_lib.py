@@ -148,8 +148,12 @@ def check_tensor(t, dtype, name):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+CALLS = [0]  # library launcher calls so far (bench.py: per pass)
+
+
 def call(name, *args, device=None):
     """Launch `name` on torch's current stream of `device` and surface library errors."""
+    CALLS[0] += 1
     l = lib()
     if _raw_stream is not None and device is not None and device.index is not None:
         stream = _raw_stream(device.index)  # the raw hipStream_t, without building a torch.cuda.Stream object

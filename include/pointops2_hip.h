@@ -183,6 +183,10 @@ size_t pointops2_fps_workspace_bytes(int b, int N);
  * idx/new_offset here: the next furthestsampling_cuda_launcher copies those samples and continues
  * instead of starting over.  One-shot (cleared by the launch). */
 void pointops2_set_fps_resume(const int *prev_idx, const int *prev_new_offset);
+/* One-shot hint for the next furthestsampling_cuda_launcher: unordered != 0 = the caller knows that the cloud is NOT the output of an
+ * earlier FPS in selection order (a raw scene), so the identity-prefix probe (six small launches, ~60 us in front of the sampler) is
+ * skipped.  The result is the same with or without the hint, and with a wrong hint. */
+void pointops2_set_fps_hint(int unordered);
 
 /* Key-major ("CSC") transposition of a CSR pair list, used by the backward kernels instead of
  * global float atomics.  When set (thread-local, cleared with NULLs), the *_backward_* launchers

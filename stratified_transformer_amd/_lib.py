@@ -26,6 +26,7 @@ SIGNATURES = {
     "pointops2_set_batch_count": [I],
     "pointops2_set_key_rows": [I],
     "pointops2_set_fps_resume": [P, P],
+    "pointops2_set_fps_hint": [I],
     "pointops2_set_csc": [P, P, P],
     "pointops2_csc_build": [I, I, P, P, P, P, P, P, Z],
     "furthestsampling_cuda_launcher": [I, I, P, P, P, P, P],

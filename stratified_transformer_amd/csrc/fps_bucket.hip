@@ -741,6 +741,7 @@ __global__ void fps_head_offsets_kernel(int b, int head, const int *__restrict__
 struct FpsResume {
     const int *prev_idx = nullptr;
     const int *prev_offset = nullptr;
+    bool unordered = false;  // pointops2_set_fps_hint: the caller knows the cloud is in no selection order (no identity-prefix probe)
 };
 FpsResume &fps_resume() {
     static thread_local FpsResume r;
@@ -787,7 +788,7 @@ bool fps_bucket_launch(int b, int n, int Bref, int log2B, const float *xyz, cons
     // identity-prefix verification (exact; see above): a cheap probe of the first 64 steps, then everything
     static const bool no_verify = getenv("P2_FPS_NO_VERIFY") != nullptr;
     const int *verified = nullptr;
-    if (!no_verify) {
+    if (!no_verify && !rs.unordered) {
         hipLaunchKernelGGL(fps_verify_init_kernel, dim3(div_up(b, 64)), dim3(64), 0, st, b, offset, new_offset, first_bad);
         hipLaunchKernelGGL(fps_verify_threshold_kernel, dim3(1, b), dim3(VER_T), 0, st, Bref, log2B, 1, xyz, offset, new_offset, first_bad, thr);
         hipLaunchKernelGGL(fps_verify_scan_kernel, dim3(div_up(n, VER_P), b), dim3(VER_T), 0, st, Bref, log2B, 1, 64, xyz, offset, new_offset, thr, first_bad);
@@ -889,5 +890,7 @@ void pointops2_set_fps_resume(const int *prev_idx, const int *prev_offset) {
     fps_resume().prev_idx = prev_idx;
     fps_resume().prev_offset = prev_offset;
 }
+
+void pointops2_set_fps_hint(int unordered) { fps_resume().unordered = unordered != 0; }
 
 }  // extern "C"

@@ -509,6 +509,7 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
 
     cloud_ready = {}  # transition level -> event: the level's point cloud exists (recorded on the geometry stream)
     cur_xyz, cur_off, cur_off_host = xyz, offset, offset_host
+    P.hint_unordered(xyz)  # (a raw scene: no identity-prefix probe in front of its sampler)
     if not cfg.stem_transformer:  # Stratified.forward :458-462: a TransitionDown precedes the first attention stage
         with on_geo():
             cur_xyz, cur_off, cur_off_host, _ = transition(cur_xyz, cur_off, cur_off_host)

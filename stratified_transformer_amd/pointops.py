@@ -275,6 +275,22 @@ def hint_host_offsets(tensor, values):
         _HOST_OFFSETS.pop(next(iter(_HOST_OFFSETS)))
 
 
+_UNORDERED = {}  # id(xyz) -> weakref: clouds their owner declared to be in no selection order (hint_unordered)
+
+
+def hint_unordered(xyz):
+    """Tell the sampler that `xyz` is a raw cloud, not the output of an earlier FPS kept in selection order: its calls on this
+    tensor skip the identity-prefix probe (~60 us in front of the sampler).  Same samples with or without, also if the hint is wrong."""
+    import weakref
+    key = id(xyz)
+    _UNORDERED[key] = weakref.ref(xyz, lambda _r, k=key: _UNORDERED.pop(k, None))
+
+
+def _is_unordered(xyz):
+    r = _UNORDERED.get(id(xyz))
+    return r is not None and r() is xyz
+
+
 def _host_list(t):
     hit = _HOST_OFFSETS.get((t.data_ptr(), t._version))
     return hit[0] if hit is not None else None
@@ -325,11 +341,13 @@ class FurthestSampling(Function):
             ws = torch.empty(int(l.pointops2_fps_workspace_bytes(b, n)), dtype=torch.uint8, device=xyz.device)
         l.pointops2_set_workspace(ptr(ws), ws.numel())
         l.pointops2_set_point_count(n)
+        l.pointops2_set_fps_hint(1 if _is_unordered(xyz) else 0)
         try:
             pointops_cuda.furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx)
         finally:
             l.pointops2_set_workspace(None, 0)
             l.pointops2_set_fps_resume(None, None)
+            l.pointops2_set_fps_hint(0)
         del tmp
         if n_max >= 2048:  # the bucketed kernel ran: its state can serve / resume later requests
             done = torch.cuda.Event()

@@ -323,6 +323,14 @@ void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_clu
                                         const int *ls_starts, int *cell_order, int *qcell, int *cell_desc, int *cell_qstart,
                                         int *cell_kbase, int *cell_pbase, int *cell_perm, int *parent_first, int *counts, void *ws,
                                         size_t ws_bytes);
+/* pass 1 in two halves, for a caller that builds beside the stage's sampler: `prepare` needs the two partitions only (cells = points
+ * sorted by (small, large) window, their cut into pieces, the parents) and leaves its intermediate arrays in ws, which must stay untouched
+ * until `sizes` - which needs the sampled points too (ls_starts) - has run on the same ws. */
+void pointops2_cell_plan_prepare_launcher(int N, int max_queries, const int *s_cluster, const int *l_cluster, int *cell_order,
+                                          int *parent_first, int *counts, void *ws, size_t ws_bytes);
+void pointops2_cell_plan_sizes_launcher(int N, const int *s_cluster, const int *s_starts, const int *l_cluster, const int *ls_starts,
+                                        const int *cell_order, int *qcell, int *cell_desc, int *cell_qstart, int *cell_kbase,
+                                        int *cell_pbase, int *cell_perm, int *counts, void *ws, size_t ws_bytes);
 void pointops2_cell_plan_fill_launcher(int N, const float *xyz, float window, float quant, int L, const int *s_order, const int *ls,
                                        const float *wc, const int *cell_order, const int *qcell, const int *cell_qstart,
                                        const int *cell_desc, const int *cell_kbase, const int *cell_pbase, int *cell_keys, int *kcell,

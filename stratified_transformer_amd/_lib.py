@@ -75,6 +75,8 @@ SIGNATURES = {
     "pointops2_voxel_keys_launcher": [I, I, P, ctypes.c_double, P],
     "pointops2_crop_dist_launcher": [I, I, P, I, P],
     "pointops2_cell_plan_count_launcher": [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z],
+    "pointops2_cell_plan_prepare_launcher": [I, I, P, P, P, P, P, P, Z],
+    "pointops2_cell_plan_sizes_launcher": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, Z],
     "pointops2_cell_plan_fill_launcher": [I, P, F, F, I, P, P, P, P, P, P, P, P, P, P, P, P],
     "cell_attention_forward_launcher": [P, I, I, I] + [P] * 9,
     "cell_attention_backward_launcher": [P, I, I, I] + [P] * 16,

@@ -584,59 +584,96 @@ size_t pointops2_cell_plan_workspace_bytes(int N) {
 // pass 1 (no host sync needed before it): cells of one block pattern from its small / large partitions and the
 // bucketed samples; max_queries > 0 cuts cells into pieces of at most that many queries.  All outputs caller-allocated: cell_order, qcell, cell_perm [N]; cell_desc [4N]; cell_qstart,
 // cell_kbase, cell_pbase, parent_first [N+2]; counts [8] = {cells, tile entries P, key slots K, largest key count, parents}.
-void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_cluster, const int *s_starts, const int *l_cluster,
-                                        const int *ls_starts, int *cell_order, int *qcell, int *cell_desc, int *cell_qstart,
-                                        int *cell_kbase, int *cell_pbase, int *cell_perm, int *parent_first, int *counts, void *ws,
-                                        size_t ws_bytes) {
-    if (N <= 0) return;
-    if (ws_bytes < pointops2_cell_plan_workspace_bytes(N)) { set_error("pointops2_cell_plan_count: workspace too small"); return; }
-    hipStream_t st = state().stream;
+// The workspace of one pattern's plan: the first pass leaves flags / rank / the uncut ranks in it for the second
+struct CellWs {
+    unsigned long long *keys_in, *keys_out;
+    int *vals_in, *flags, *rank, *nk_of, *tile_of;
+    unsigned *work_key;
+    void *tmp;
+    size_t tmp_bytes;
+};
+static CellWs cell_ws(int N, void *ws, size_t ws_bytes) {
+    CellWs w;
     char *p = reinterpret_cast<char *>(ws);
-    unsigned long long *keys_in = (unsigned long long *)p; p += al((size_t)N * 8);
-    unsigned long long *keys_out = (unsigned long long *)p; p += al((size_t)N * 8);
-    int *vals_in = (int *)p; p += al(((size_t)N + 2) * 4);
-    int *flags = (int *)p; p += al(((size_t)N + 2) * 4);
-    int *rank = (int *)p; p += al(((size_t)N + 2) * 4);
-    int *nk_of = (int *)p; p += al(((size_t)N + 2) * 4);
-    int *tile_of = (int *)p; p += al(((size_t)N + 2) * 4);
-    unsigned *work_key = (unsigned *)p; p += al(((size_t)N + 2) * 4);
-    void *tmp = p;
-    size_t tmp_bytes = ws_bytes - (size_t)(p - reinterpret_cast<char *>(ws));
+    w.keys_in = (unsigned long long *)p; p += al((size_t)N * 8);
+    w.keys_out = (unsigned long long *)p; p += al((size_t)N * 8);
+    w.vals_in = (int *)p; p += al(((size_t)N + 2) * 4);
+    w.flags = (int *)p; p += al(((size_t)N + 2) * 4);
+    w.rank = (int *)p; p += al(((size_t)N + 2) * 4);
+    w.nk_of = (int *)p; p += al(((size_t)N + 2) * 4);
+    w.tile_of = (int *)p; p += al(((size_t)N + 2) * 4);
+    w.work_key = (unsigned *)p; p += al(((size_t)N + 2) * 4);
+    w.tmp = p;
+    w.tmp_bytes = ws_bytes - (size_t)(p - reinterpret_cast<char *>(ws));
+    return w;
+}
+
+// pass 1a: what needs the two partitions only - the cells (points sorted by (small, large) window), their cut into pieces of at most
+// max_queries queries, the parents.  A caller runs it BESIDE the stage's sampler; `ws` must stay untouched until pass 1b has run.
+void pointops2_cell_plan_prepare_launcher(int N, int max_queries, const int *s_cluster, const int *l_cluster, int *cell_order,
+                                          int *parent_first, int *counts, void *ws, size_t ws_bytes) {
+    if (N <= 0) return;
+    if (ws_bytes < pointops2_cell_plan_workspace_bytes(N)) { set_error("pointops2_cell_plan_prepare: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    CellWs w = cell_ws(N, ws, ws_bytes);
     const int g = div_up(N, 256);
     int lbits = 1;
     while ((1ll << lbits) <= (long long)N) lbits++;  // window ids are < N
     (void)hipMemsetAsync(counts, 0, 8 * sizeof(int), st);
-    hipLaunchKernelGGL(cell_key_kernel, dim3(g), dim3(256), 0, st, N, lbits, s_cluster, l_cluster, keys_in, vals_in);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const unsigned long long *)keys_in, keys_out, (const int *)vals_in,
-                                                      cell_order, N, 0, 2 * lbits, st);
+    hipLaunchKernelGGL(cell_key_kernel, dim3(g), dim3(256), 0, st, N, lbits, s_cluster, l_cluster, w.keys_in, w.vals_in);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(w.tmp, w.tmp_bytes, (const unsigned long long *)w.keys_in, w.keys_out,
+                                                      (const int *)w.vals_in, cell_order, N, 0, 2 * lbits, st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
-    hipLaunchKernelGGL(boundary_flag_kernel, dim3(g), dim3(256), 0, st, N, keys_out, flags);
-    e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, N, st);
+    hipLaunchKernelGGL(boundary_flag_kernel, dim3(g), dim3(256), 0, st, N, w.keys_out, w.flags);
+    e = hipcub::DeviceScan::InclusiveSum(w.tmp, w.tmp_bytes, (const int *)w.flags, w.rank, N, st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
     // (nk_of, tile_of and work_key are still free: first position of every uncut run, uncut rank, cut rank)
-    int *prank = tile_of, *srank = reinterpret_cast<int *>(work_key);
-    hipLaunchKernelGGL(cell_run_start_kernel, dim3(g), dim3(256), 0, st, N, flags, rank, nk_of);
-    (void)hipMemcpyAsync(prank, rank, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st);
+    int *prank = w.tile_of, *srank = reinterpret_cast<int *>(w.work_key);
+    hipLaunchKernelGGL(cell_run_start_kernel, dim3(g), dim3(256), 0, st, N, w.flags, w.rank, w.nk_of);
+    (void)hipMemcpyAsync(prank, w.rank, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st);
     if (max_queries > 0) {
-        hipLaunchKernelGGL(cell_split_flag_kernel, dim3(g), dim3(256), 0, st, N, max_queries, rank, nk_of, flags);
-        e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (const int *)flags, rank, N, st);
+        hipLaunchKernelGGL(cell_split_flag_kernel, dim3(g), dim3(256), 0, st, N, max_queries, w.rank, w.nk_of, w.flags);
+        e = hipcub::DeviceScan::InclusiveSum(w.tmp, w.tmp_bytes, (const int *)w.flags, w.rank, N, st);
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
     }
-    (void)hipMemcpyAsync(srank, rank, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st);
-    hipLaunchKernelGGL(cell_parent_kernel, dim3(g), dim3(256), 0, st, N, flags, srank, prank, nk_of, parent_first, counts);
-    hipLaunchKernelGGL(cell_describe_kernel, dim3(g), dim3(256), 0, st, N, cell_order, flags, rank, s_cluster, s_starts, l_cluster, ls_starts,
-                       qcell, cell_qstart, cell_desc, nk_of, counts);
+    (void)hipMemcpyAsync(srank, w.rank, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(cell_parent_kernel, dim3(g), dim3(256), 0, st, N, w.flags, srank, prank, w.nk_of, parent_first, counts);
+    check_launch();
+}
+
+// pass 1b: what needs the sampled points too (ls_starts) - key counts, tile sizes, their scans, the work order, the totals
+void pointops2_cell_plan_sizes_launcher(int N, const int *s_cluster, const int *s_starts, const int *l_cluster, const int *ls_starts,
+                                        const int *cell_order, int *qcell, int *cell_desc, int *cell_qstart, int *cell_kbase,
+                                        int *cell_pbase, int *cell_perm, int *counts, void *ws, size_t ws_bytes) {
+    if (N <= 0) return;
+    if (ws_bytes < pointops2_cell_plan_workspace_bytes(N)) { set_error("pointops2_cell_plan_sizes: workspace too small"); return; }
+    hipStream_t st = state().stream;
+    CellWs w = cell_ws(N, ws, ws_bytes);
+    const int g = div_up(N, 256);
+    hipLaunchKernelGGL(cell_describe_kernel, dim3(g), dim3(256), 0, st, N, cell_order, w.flags, w.rank, s_cluster, s_starts, l_cluster, ls_starts,
+                       qcell, cell_qstart, cell_desc, w.nk_of, counts);
     // (vals_in is free again: the ids of the work-order sort)
-    hipLaunchKernelGGL(cell_tile_kernel, dim3(div_up(N + 1, 256)), dim3(256), 0, st, N, counts, cell_qstart, nk_of, tile_of, work_key, vals_in);
-    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, (const int *)nk_of, cell_kbase, N + 1, st);
+    hipLaunchKernelGGL(cell_tile_kernel, dim3(div_up(N + 1, 256)), dim3(256), 0, st, N, counts, cell_qstart, w.nk_of, w.tile_of, w.work_key, w.vals_in);
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, (const int *)w.nk_of, cell_kbase, N + 1, st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
-    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, (const int *)tile_of, cell_pbase, N + 1, st);
+    e = hipcub::DeviceScan::ExclusiveSum(w.tmp, w.tmp_bytes, (const int *)w.tile_of, cell_pbase, N + 1, st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
-    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const unsigned *)work_key, (unsigned *)keys_out, (const int *)vals_in, cell_perm, N,
-                                           0, 32, st);
+    e = hipcub::DeviceRadixSort::SortPairs(w.tmp, w.tmp_bytes, (const unsigned *)w.work_key, (unsigned *)w.keys_out, (const int *)w.vals_in,
+                                           cell_perm, N, 0, 32, st);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return; }
     hipLaunchKernelGGL(cell_totals_kernel, dim3(1), dim3(64), 0, st, N, cell_kbase, cell_pbase, counts);
     check_launch();
+}
+
+// pass 1 in one call (1a + 1b)
+void pointops2_cell_plan_count_launcher(int N, int max_queries, const int *s_cluster, const int *s_starts, const int *l_cluster,
+                                        const int *ls_starts, int *cell_order, int *qcell, int *cell_desc, int *cell_qstart,
+                                        int *cell_kbase, int *cell_pbase, int *cell_perm, int *parent_first, int *counts, void *ws,
+                                        size_t ws_bytes) {
+    pointops2_cell_plan_prepare_launcher(N, max_queries, s_cluster, l_cluster, cell_order, parent_first, counts, ws, ws_bytes);
+    if (state().error != nullptr) return;
+    pointops2_cell_plan_sizes_launcher(N, s_cluster, s_starts, l_cluster, ls_starts, cell_order, qcell, cell_desc, cell_qstart, cell_kbase,
+                                       cell_pbase, cell_perm, counts, ws, ws_bytes);
 }
 
 // pass 2 (the caller has read counts and allocated cell_keys / kcell [K] and relp [P]): key lists and packed rel-pos tiles

@@ -279,7 +279,7 @@ class _KeyOverflow(Exception):
 FUSED_PARTITIONS = os.environ.get("P2_PARTITIONS4", "1") != "0"
 
 
-def stage_partitions_hip(xyz, offset, window_size, one_sort=None):
+def stage_partitions_hip(xyz, offset, window_size, one_sort=None, cell_max_queries=None):
     """The part of a stage's index build that needs the coordinates only: bounding box and the four window partitions
     (grid_sample x 4, stratified_transformer.py:277,280,297,300).  Returns the context stage_index_hip continues from - a caller
     can run this beside the stage's FPS instead of behind it.
@@ -287,7 +287,11 @@ def stage_partitions_hip(xyz, offset, window_size, one_sort=None):
     one_sort (default): all four partitions by ONE radix sort on a key of fixed width (csrc/index.hip, voxel_key4_kernel) and no
     host sync; `overflow` (a device flag the next read-back of stage_index_hip looks at) says that a voxel coordinate needed more
     than ten bits - stage_index_hip then comes back here with one_sort=False: one sort per partition, the key sized from the
-    bounding box on the host (one sync), any extent."""
+    bounding box on the host (one sync), any extent.
+
+    cell_max_queries (>= 0; None = no cell plans wanted): also the half of the cell plans' first pass that needs the partitions only
+    (pointops2_cell_plan_prepare_launcher: the cells, their cut into pieces, the parents - ~22 of the ~38 launches of that pass), so
+    that a caller who runs this beside the stage's sampler has them off the path between the sampler's end and the first block."""
     import numpy as np
     from . import _lib
     from ._lib import ptr
@@ -326,7 +330,23 @@ def stage_partitions_hip(xyz, offset, window_size, one_sort=None):
                 _lib.call("pointops2_window_partition_launcher", N, b, ptr(xyz), ptr(offset), ptr(bbox), float(size), float(shift), key_bits,
                           ptr(part.cluster), ptr(part.order), ptr(part.starts), ptr(part.n_windows), ptr(ws), ws_bytes, device=dev)
                 parts[name] = part
-    return dict(parts=parts, ws=ws, ws_bytes=ws_bytes, bbox=bbox, w32=w32, overflow=overflow)
+        prepared = None
+        if cell_max_queries is not None and N > 0:
+            prepared = {"cap": int(cell_max_queries)}
+            cws_bytes = int(l.pointops2_cell_plan_workspace_bytes(N))
+            for shifted, sname, lname in ((0, "small", "large"), (1, "small_shift", "large_shift")):
+                cells = _new_cells(N, i32)
+                cws = torch.empty(cws_bytes, dtype=torch.uint8, device=dev)   # (its own: it carries the pass's state to stage_index_hip)
+                _lib.call("pointops2_cell_plan_prepare_launcher", N, int(cell_max_queries), ptr(parts[sname].cluster), ptr(parts[lname].cluster),
+                          ptr(cells["cell_order"]), ptr(cells["parent_first"]), ptr(cells["counts"]), ptr(cws), cws_bytes, device=dev)
+                prepared[shifted] = (cells, cws, cws_bytes)
+    return dict(parts=parts, ws=ws, ws_bytes=ws_bytes, bbox=bbox, w32=w32, overflow=overflow, cells_prepared=prepared)
+
+
+def _new_cells(N, i32):
+    return dict(counts=torch.empty(8, **i32), parent_first=torch.empty(N + 2, **i32), cell_perm=torch.empty(N, **i32), cell_desc=torch.empty((N, 4), **i32),
+                cell_qstart=torch.empty(N + 2, **i32), cell_kbase=torch.empty(N + 2, **i32), cell_pbase=torch.empty(N + 2, **i32),
+                cell_order=torch.empty(N, **i32), qcell=torch.empty(N, **i32))
 
 
 def stage_index_hip(xyz, offset, window_size, quant_size, downsample_idx, cell_table_rows=None, cell_max_queries=0, partitions=None,
@@ -429,15 +449,22 @@ def _stage_index_hip(ctx, xyz, offset, quant_size, downsample_idx, cell_table_ro
                  ptr(offsets), ptr(ws), ws_bytes)
             cells = None
             if cell_table_rows is not None:
-                cws_bytes = int(l.pointops2_cell_plan_workspace_bytes(N))
-                cws = ws if cws_bytes <= ws_bytes else torch.empty(cws_bytes, dtype=torch.uint8, device=dev)
-                cells = dict(counts=torch.empty(8, **i32), parent_first=torch.empty(N + 2, **i32), cell_perm=torch.empty(N, **i32), cell_desc=torch.empty((N, 4), **i32),
-                             cell_qstart=torch.empty(N + 2, **i32), cell_kbase=torch.empty(N + 2, **i32), cell_pbase=torch.empty(N + 2, **i32),
-                             cell_order=torch.empty(N, **i32), qcell=torch.empty(N, **i32))
-                call("pointops2_cell_plan_count_launcher", N, int(cell_max_queries), ptr(s.cluster), ptr(s.starts), ptr(lg.cluster), ptr(ls_starts),
-                     ptr(cells["cell_order"]), ptr(cells["qcell"]), ptr(cells["cell_desc"]), ptr(cells["cell_qstart"]), ptr(cells["cell_kbase"]),
-                     ptr(cells["cell_pbase"]), ptr(cells["cell_perm"]), ptr(cells["parent_first"]), ptr(cells["counts"]), ptr(cws),
-                     max(cws_bytes, ws_bytes))
+                ready = ctx.get("cells_prepared")
+                if ready is not None and ready.get("cap") == int(cell_max_queries) and shifted in ready and not ctx.get("cells_prepared_used", {}).get(shifted):
+                    # the first half of the pass ran with the partitions (stage_partitions_hip): only what needs the samples is left
+                    cells, cws, cws_bytes = ready[shifted]
+                    ctx.setdefault("cells_prepared_used", {})[shifted] = True   # (its arrays become this build's plan: not handed out twice)
+                    call("pointops2_cell_plan_sizes_launcher", N, ptr(s.cluster), ptr(s.starts), ptr(lg.cluster), ptr(ls_starts), ptr(cells["cell_order"]),
+                         ptr(cells["qcell"]), ptr(cells["cell_desc"]), ptr(cells["cell_qstart"]), ptr(cells["cell_kbase"]), ptr(cells["cell_pbase"]),
+                         ptr(cells["cell_perm"]), ptr(cells["counts"]), ptr(cws), cws_bytes)
+                else:
+                    cws_bytes = int(l.pointops2_cell_plan_workspace_bytes(N))
+                    cws = ws if cws_bytes <= ws_bytes else torch.empty(cws_bytes, dtype=torch.uint8, device=dev)
+                    cells = _new_cells(N, i32)
+                    call("pointops2_cell_plan_count_launcher", N, int(cell_max_queries), ptr(s.cluster), ptr(s.starts), ptr(lg.cluster), ptr(ls_starts),
+                         ptr(cells["cell_order"]), ptr(cells["qcell"]), ptr(cells["cell_desc"]), ptr(cells["cell_qstart"]), ptr(cells["cell_kbase"]),
+                         ptr(cells["cell_pbase"]), ptr(cells["cell_perm"]), ptr(cells["parent_first"]), ptr(cells["counts"]), ptr(cws),
+                         max(cws_bytes, ws_bytes))
             pending.append((s, lg, ls, ls_starts, wc, offsets, cells, shifted))
             if on_even is not None and shifted == 0:
                 # the caller wants the plain pattern as soon as it exists (its first block runs beside the shifted pattern's

@@ -557,7 +557,9 @@ def scene_pass_phases(xyz, offset, cfg, states=None, timer=None, seed=0, overlap
                 lvl = si - first + (0 if cfg.stem_transformer else 1)
                 if overlap and lvl in cloud_ready:
                     idx_s.wait_event(cloud_ready[lvl])
-                parts_ctx = timer.run("index/partitions", index_build.stage_partitions_hip, x, off, st.window_size)
+                want_cells = cells or str(fused).startswith("cell")
+                parts_ctx = timer.run("index/partitions", index_build.stage_partitions_hip, x, off, st.window_size, None,
+                                      index_build.cell_query_cap(x.shape[0], st.num_heads) if want_cells else None)
             if overlap and ev_ds is not None:
                 idx_s.wait_event(ev_ds)
             if use_hip_index:

@@ -618,6 +618,84 @@ def test_partitions_by_one_sort_equal_the_four_single_sorts(sizes, w):
         assert torch.equal(a.starts[: nw + 1], b.starts[: nw + 1]), name
 
 
+@pytest.mark.parametrize("case", ["one_point", "five_coincident_points", "tiny_batch_elements"])
+def test_partitions_by_one_sort_on_degenerate_clouds(case):
+    """one point; coincident points (one window); batch elements of 1 and 2 points beside a larger one"""
+    from stratified_transformer_amd import index_build
+    rng = np.random.default_rng(5)
+    if case == "one_point":
+        xyz_np, offset = np.array([[0.3, 0.2, 0.1]], np.float32), np.array([1], np.int32)
+    elif case == "five_coincident_points":
+        xyz_np, offset = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (5, 1)), np.array([5], np.int32)
+    else:
+        xyz_np = np.concatenate([rng.random((1, 3)), rng.random((2, 3)) * 0.1, rng.random((700, 3)) * 2.0]).astype(np.float32)
+        offset = np.array([1, 3, 703], np.int32)
+    xyz, off = dev(xyz_np), dev(offset)
+    one = index_build.stage_partitions_hip(xyz, off, 0.16, one_sort=True)
+    four = index_build.stage_partitions_hip(xyz, off, 0.16, one_sort=False)
+    assert int(one["overflow"].item()) == 0
+    for name in ("small", "small_shift", "large", "large_shift"):
+        a, b = one["parts"][name], four["parts"][name]
+        nw = int(b.n_windows.item())
+        assert int(a.n_windows.item()) == nw and torch.equal(a.cluster, b.cluster) and torch.equal(a.order, b.order), (case, name)
+        assert torch.equal(a.starts[: nw + 1], b.starts[: nw + 1]), (case, name)
+
+
+def test_fps_with_a_wrong_unordered_hint_returns_the_same_samples(P):
+    """pointops.hint_unordered only skips the identity-prefix probe: on a cloud that IS in selection order the sampler then walks the
+    whole chain itself and must return the same 0, 1, 2, ... (and the oracle's samples on a raw cloud, hinted or not)."""
+    from stratified_transformer_amd import scene
+    xyz = scene.make_room(9000, 13)
+    order = ref.furthestsampling(xyz, np.array([9000], np.int32), np.array([2400], np.int32))
+    sub = np.ascontiguousarray(xyz[order])
+    for cloud, n, m in ((sub, 2400, 900), (xyz, 9000, 1126)):
+        want = ref.furthestsampling(cloud, np.array([n], np.int32), np.array([m], np.int32))
+        x, off, new = dev(cloud), dev(np.array([n], np.int32)), dev(np.array([m], np.int32))
+        P.clear_caches()
+        plain = _np(P.furthestsampling(x, off, new))
+        P.clear_caches()
+        P.hint_unordered(x)
+        hinted = _np(P.furthestsampling(x, off, new))
+        assert np.array_equal(plain, want) and np.array_equal(hinted, want)
+    assert np.array_equal(hinted[:10], want[:10])
+
+
+def test_row_order_with_empty_rows_and_an_arbitrary_pair_list(P):
+    """rows without partners go last in the window order; an arbitrary CSR (not a window structure at all) still gives the same A1
+    logits and gradients in either order"""
+    n, h, M = 3000, 2, 40000
+    rng = np.random.default_rng(9)
+    counts = rng.multinomial(M, np.ones(n) / n).astype(np.int64)
+    counts[rng.choice(n, 300, replace=False)] = 0
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    M = int(offsets[-1])
+    index1 = rng.integers(0, n, M).astype(np.int32)
+    offs_d, idx_d = dev(offsets), dev(index1)
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(n, h, 16, generator=g).cuda().requires_grad_(True)
+    k = torch.randn(n, h, 16, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(M, h, generator=g).cuda()
+    outs = {}
+    was = P.ROW_ORDER
+    try:
+        for on in (False, True):
+            P.ROW_ORDER = on
+            P.clear_caches()
+            q.grad = k.grad = None
+            a = P.attention_step1_v2(q, k, idx_d, offs_d, torch.tensor(int(counts.max()), device="cuda"))
+            a.backward(go)
+            torch.cuda.synchronize()
+            outs[on] = (a.detach().clone(), q.grad.clone(), k.grad.clone())
+        order = _np(P.row_order_of(offs_d, idx_d))
+    finally:
+        P.ROW_ORDER = was
+    for x, y in zip(outs[False], outs[True]):
+        assert torch.equal(x, y)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    empty = counts[order] == 0
+    assert not empty[: n - int(empty.sum())].any() and empty[n - int(empty.sum()):].all()   # the rows without partners: last
+
+
 def test_index_build_of_a_scene_wider_than_the_fixed_key():
     """More than 1024 windows along an axis: the one-sort partitions flag the overflow, stage_index_hip notices at its read-back and
     builds the partitions one by one (host-sized keys) - the pair lists are the oracle's."""

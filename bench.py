@@ -80,7 +80,7 @@ import gc
 
 @contextlib.contextmanager
 def no_gc():
-    """The host enqueues a pass in ~12 of its ~14 ms: a full collection of Python's cyclic garbage collector (tens of ms with the
+    """The host enqueues a pass in ~11 of its ~11.4 ms: a full collection of Python's cyclic garbage collector (tens of ms with the
     process's millions of live objects; due every few dozen passes) inside a timed region shows up as +2-4 ms per pass of a 20-step
     leg and not at all in a 5-step one.  Collected before, switched off inside (as a training loop that cares would)."""
     gc.collect()
